@@ -1,0 +1,355 @@
+"""
+oracle/gen_golden.py -- generate golden vectors by RUNNING THE REFERENCE (build container only).
+
+TEST INFRASTRUCTURE.  Imports Pyrado from /root/reference/Pyrado with the local stub harness of SURVEY.md section 8(c)
+(three absent third-party modules stubbed in sys.modules, two removed NumPy aliases restored) and dumps, for the five
+SimPyEnv families, single-step cases, short trajectories, reset cases and the default-randomizer tables as small
+``.npz`` / ``.json`` fixtures under ``tests/golden/``.  The fixtures are data (inputs + the reference's outputs);
+no reference source is copied.  Nothing here runs on the GPU box (``/root/reference`` does not exist there).
+
+Usage:  python oracle/gen_golden.py            (deterministic: fixed seeds)
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(HERE, "..", "tests", "golden")
+REF = "/root/reference/Pyrado"
+
+
+def _install_stubs():
+    sys.dont_write_bytecode = True
+    np.float = float  # removed NumPy aliases still used by the reference (Q7)
+    np.object = object
+
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    class _Blank:
+        def __getattr__(self, k):
+            return ""
+
+    mod("colorama", Style=_Blank(), Fore=_Blank(), Back=_Blank(), init=lambda **k: None)
+    mod("ipdb", set_trace=lambda *a, **k: None)
+
+    class Serializable:
+        @staticmethod
+        def _init(self, locals_):
+            pass
+
+    ias = mod("init_args_serializer", Serializable=Serializable)
+    ias.serializable = mod("init_args_serializer.serializable", Serializable=Serializable)
+    sys.path.insert(0, REF)
+
+
+_install_stubs()
+import torch  # noqa: E402
+
+import pyrado  # noqa: E402
+from pyrado.domain_randomization.default_randomizers import create_default_randomizer  # noqa: E402
+from pyrado.environments.pysim.ball_on_beam import BallOnBeamSim  # noqa: E402
+from pyrado.environments.pysim.one_mass_oscillator import OneMassOscillatorSim  # noqa: E402
+from pyrado.environments.pysim.quanser_ball_balancer import QBallBalancerSim  # noqa: E402
+from pyrado.environments.pysim.quanser_cartpole import QCartPoleSwingUpSim  # noqa: E402
+from pyrado.environments.pysim.quanser_qube import QQubeSwingUpSim  # noqa: E402
+
+# env kwargs = Pyrado/tests/conftest.py:160-193
+ENVS = {
+    "omo": (OneMassOscillatorSim, dict(dt=0.02, max_steps=300)),
+    "bob": (BallOnBeamSim, dict(dt=0.01, max_steps=500)),
+    "qq-su": (QQubeSwingUpSim, dict(dt=0.004, max_steps=4000)),
+    "qcp-su": (QCartPoleSwingUpSim, dict(dt=0.002, max_steps=8000)),
+    "qbb": (QBallBalancerSim, dict(dt=0.01, max_steps=500)),
+}
+HIDDEN = {"omo": 0, "bob": 0, "qq-su": 0, "qcp-su": 1, "qbb": 2}
+
+
+def get_hidden(name, env):
+    if name == "qcp-su":
+        return np.array([float(env._th_ddot)])
+    if name == "qbb":
+        return np.array(env.plate_angs, dtype=np.float64).copy()
+    return np.zeros(0)
+
+
+def set_hidden(name, env, h):
+    if name == "qcp-su":
+        env._th_ddot = float(h[0])
+    elif name == "qbb":
+        env.plate_angs = np.array(h, dtype=np.float64).copy()
+
+
+def param_names(env):
+    return list(env.get_nominal_domain_param().keys())
+
+
+def params_to_vec(env, dp):
+    return np.array([float(dp[k]) for k in param_names(env)], dtype=np.float64)
+
+
+def vec_to_params(env, vec):
+    return {k: float(v) for k, v in zip(param_names(env), vec)}
+
+
+def draw_params(name, env, rng, randomizer, mode):
+    """mode 0: nominal, 1: default randomizer draw (fp32 values, Q13), 2: like 1 plus non-trivial dead-zone tholds"""
+    dp = env.get_nominal_domain_param()
+    if mode >= 1:
+        randomizer.randomize(num_samples=1)
+        for k, v in randomizer.get_params(fmt="dict", dtype="numpy").items():
+            dp[k] = float(v)
+    if mode == 2 and name in ("qq-su", "qcp-su"):
+        dp["voltage_thold_neg"] = float(np.float32(-rng.uniform(0.05, 0.6)))
+        dp["voltage_thold_pos"] = float(np.float32(rng.uniform(0.05, 0.6)))
+    return dp
+
+
+def space_info(env):
+    out = dict(state_lo=env.state_space.bound_lo, state_hi=env.state_space.bound_up,
+               act_lo=env.act_space.bound_lo, act_hi=env.act_space.bound_up)
+    c_max = getattr(env.task.rew_fcn, "c_max", None) if hasattr(env.task, "rew_fcn") else None
+    out["c_max"] = np.array(np.nan if c_max is None else float(c_max))
+    return {k: np.array(v, dtype=np.float64) for k, v in out.items()}
+
+
+def gen_step_cases(name, m, seed):
+    cls, kw = ENVS[name]
+    env = cls(**kw)
+    rng = np.random.default_rng(seed)
+    torch.manual_seed(seed)
+    randomizer = create_default_randomizer(env)
+    rec = {k: [] for k in ("params", "state", "hidden", "act", "curr_step", "nstate", "nhidden", "obs", "rew", "done",
+                           "state_lo", "state_hi", "act_lo", "act_hi", "c_max")}
+    H = HIDDEN[name]
+    for i in range(m):
+        dp = draw_params(name, env, rng, randomizer, i % 3)
+        env.reset(init_state=np.zeros(env.state_space.shape), domain_param=dp)  # applies params, constants, spaces
+        info = space_info(env)
+        lo, hi = info["state_lo"], info["state_hi"]
+        # state: inside the box; every 6th case hugs one face (done flips), every 7th has one coord outside
+        u = rng.uniform(-1, 1, size=lo.shape)
+        if i % 6 == 0:
+            j = rng.integers(lo.size)
+            u[j] = np.sign(u[j]) * rng.uniform(0.9995, 1.0005)
+        if i % 7 == 0:
+            j = rng.integers(lo.size)
+            u[j] = np.sign(u[j]) * rng.uniform(1.0, 1.05)
+        state = 0.5 * (lo + hi) + 0.5 * (hi - lo) * u
+        if H == 1:
+            hidden = rng.uniform(-120, 120, size=1)
+        elif H == 2:
+            hidden = rng.uniform(-0.3, 0.3, size=2)
+        else:
+            hidden = np.zeros(0)
+        amax = info["act_hi"]
+        act = rng.uniform(-1.5, 1.5, size=amax.shape) * amax
+        if i % 5 == 0:
+            act = rng.uniform(-0.3, 0.3, size=amax.shape)  # small -> dead-zone candidates
+        if i % 11 == 0:
+            act = np.zeros_like(amax)
+        max_steps = kw["max_steps"]
+        curr = int(rng.integers(0, max_steps - 1))
+        if i % 9 == 0:
+            curr = max_steps - 1  # this step times out
+        env.state = state.copy()
+        env._curr_step = curr
+        set_hidden(name, env, hidden)
+        obs, rew, done, _ = env.step(act.copy())
+        rec["params"].append(params_to_vec(env, env.domain_param))
+        rec["state"].append(state)
+        rec["hidden"].append(hidden)
+        rec["act"].append(act)
+        rec["curr_step"].append(curr)
+        rec["nstate"].append(np.array(env.state, dtype=np.float64).copy())
+        rec["nhidden"].append(get_hidden(name, env))
+        rec["obs"].append(np.array(obs, dtype=np.float64))
+        rec["rew"].append(float(rew))
+        rec["done"].append(bool(done))
+        for k in ("state_lo", "state_hi", "act_lo", "act_hi", "c_max"):
+            rec[k].append(info[k])
+    out = {k: np.array(v) for k, v in rec.items()}
+    out["dt"] = np.array(kw["dt"])
+    out["max_steps"] = np.array(kw["max_steps"])
+    out["param_names"] = np.array(param_names(env))
+    return out
+
+
+def gen_traj(name, n_traj, t_max, seed, extra_after_done=3):
+    """reset(init_state, domain_param) followed by up to t_max random-action steps; keeps stepping a few steps after
+    done (rollout(stop_on_done=False) semantics) so the once-only final reward is covered."""
+    cls, kw = ENVS[name]
+    env = cls(**kw)
+    rng = np.random.default_rng(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    randomizer = create_default_randomizer(env)
+    S = env.state_space.shape[0]
+    A = env.act_space.shape[0]
+    O = env.obs_space.shape[0]
+    H = HIDDEN[name]
+    P = len(param_names(env))
+    z = lambda *s: np.full(s, np.nan)  # noqa: E731
+    out = dict(params=z(n_traj, P), init=[], reset_obs=[], length=np.zeros(n_traj, dtype=np.int64),
+               act=z(n_traj, t_max, A), state=z(n_traj, t_max + 1, S), hidden=z(n_traj, t_max + 1, H),
+               obs=z(n_traj, t_max, O), rew=z(n_traj, t_max), done=np.zeros((n_traj, t_max), dtype=bool))
+    for i in range(n_traj):
+        dp = draw_params(name, env, rng, randomizer, 0 if i < n_traj // 2 else 1)
+        env.reset(domain_param=dp)  # spaces for these params
+        init = env.init_space.sample_uniform()
+        if name in ("omo", "bob") and i % 2 == 1:
+            # start close to a bound so the episode fails early (covers failure malus / done)
+            init = np.array(init)
+            init[0] = 0.97 * env.state_space.bound_up[0]
+            init = np.concatenate([init]) if init.shape == env.state_space.shape else init
+        robs = env.reset(init_state=np.array(init, dtype=np.float64), domain_param=dp)
+        out["params"][i] = params_to_vec(env, env.domain_param)
+        out["init"].append(np.array(init, dtype=np.float64))
+        out["reset_obs"].append(np.array(robs, dtype=np.float64))
+        out["state"][i, 0] = env.state
+        out["hidden"][i, 0] = get_hidden(name, env)
+        after = 0
+        amax = env.act_space.bound_up
+        for t in range(t_max):
+            act = rng.uniform(-1.2, 1.2, size=amax.shape) * amax
+            obs, rew, done, _ = env.step(act.copy())
+            out["act"][i, t] = act
+            out["obs"][i, t] = obs
+            out["rew"][i, t] = rew
+            out["done"][i, t] = done
+            out["state"][i, t + 1] = env.state
+            out["hidden"][i, t + 1] = get_hidden(name, env)
+            out["length"][i] = t + 1
+            if done:
+                after += 1
+                if after > extra_after_done:
+                    break
+    out["init"] = np.array(out["init"])
+    out["reset_obs"] = np.array(out["reset_obs"])
+    out["dt"] = np.array(kw["dt"])
+    out["max_steps"] = np.array(kw["max_steps"])
+    return out
+
+
+def gen_reset(name, m, seed):
+    """reset() with explicit init states of init-space shape and of full-state shape, nominal + randomised params"""
+    cls, kw = ENVS[name]
+    env = cls(**kw)
+    rng = np.random.default_rng(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    randomizer = create_default_randomizer(env)
+    rec = {k: [] for k in ("params", "init", "full", "state", "hidden", "obs", "state_lo", "state_hi", "act_lo",
+                           "act_hi", "c_max", "init_lo", "init_hi")}
+    for i in range(m):
+        dp = draw_params(name, env, rng, randomizer, i % 2)
+        env.reset(domain_param=dp)
+        full = bool(i % 4 >= 2)
+        if full:
+            lo, hi = env.state_space.bound_lo, env.state_space.bound_up
+            init = rng.uniform(0.5 * lo, 0.5 * hi)
+            pad = init
+        else:
+            init = np.array(env.init_space.sample_uniform(), dtype=np.float64)
+            pad = np.concatenate([init, np.full(env.state_space.shape[0] - init.shape[0], np.nan)])
+        obs = env.reset(init_state=init.copy(), domain_param=dp)
+        info = space_info(env)
+        rec["params"].append(params_to_vec(env, env.domain_param))
+        rec["init"].append(pad)
+        rec["full"].append(full)
+        rec["state"].append(np.array(env.state, dtype=np.float64).copy())
+        rec["hidden"].append(get_hidden(name, env))
+        rec["obs"].append(np.array(obs, dtype=np.float64))
+        for k in ("state_lo", "state_hi", "act_lo", "act_hi", "c_max"):
+            rec[k].append(info[k])
+        if name == "bob":
+            sp = env.init_space.subspace(0)
+            sp1 = env.init_space.subspace(1)
+            rec["init_lo"].append(np.concatenate([sp.bound_lo, sp1.bound_lo]))
+            rec["init_hi"].append(np.concatenate([sp.bound_up, sp1.bound_up]))
+        else:
+            rec["init_lo"].append(env.init_space.bound_lo)
+            rec["init_hi"].append(env.init_space.bound_up)
+    return {k: np.array(v) for k, v in rec.items()}
+
+
+def gen_cfg1():
+    """BASELINE.json configs[0] / SURVEY 8(d) config 1: OMO, 1 env, 500 forward-Euler steps, actions U(-30, 30)"""
+    env = OneMassOscillatorSim(dt=0.02, max_steps=500)
+    rng = np.random.default_rng(0)
+    obs0 = env.reset(init_state=np.array([-0.7, 0.0]))
+    acts, states, rews, dones = [], [np.array(env.state)], [], []
+    for _ in range(500):
+        a = rng.uniform(-30, 30, size=1)
+        obs, rew, done, _ = env.step(a.copy())
+        acts.append(a)
+        states.append(np.array(env.state))
+        rews.append(rew)
+        dones.append(done)
+    return dict(obs0=obs0, act=np.array(acts), state=np.array(states), rew=np.array(rews), done=np.array(dones))
+
+
+def gen_randomizer_tables():
+    tables = {}
+    for name, (cls, kw) in ENVS.items():
+        env = cls(**kw)
+        rows = []
+        for dp in create_default_randomizer(env).domain_params:
+            kind = type(dp).__name__
+            row = dict(name=dp.name, kind=kind, mean=float(dp.mean), clip_lo=float(dp.clip_lo),
+                       clip_up=float(dp.clip_up))
+            row["spread"] = float(dp.std) if kind == "NormalDomainParam" else float(dp.halfspan)
+            rows.append(row)
+        tables[name] = dict(nominal={k: float(v) for k, v in env.get_nominal_domain_param().items()}, randomizer=rows)
+    return tables
+
+
+def gen_ik(seed=3):
+    """QBallBalancerKin on a sweep of servo angles and geometries (torch fp32 SGD, Q8)"""
+    env = QBallBalancerSim(dt=0.01, max_steps=500)
+    rng = np.random.default_rng(seed)
+    th, r, l, ang = [], [], [], []  # noqa: E741
+    for i in range(48):
+        dp = env.get_nominal_domain_param()
+        if i >= 16:
+            dp["arm_radius"] = float(np.float32(rng.uniform(0.018, 0.033)))
+            dp["plate_length"] = float(np.float32(rng.uniform(0.2, 0.35)))
+        env.reset(domain_param=dp)
+        t = float(rng.uniform(-0.6, 0.6)) if i % 4 else 0.0
+        th.append(t)
+        r.append(dp["arm_radius"])
+        l.append(dp["plate_length"] / 2.0)
+        ang.append(env._kin(t))
+    return dict(th=np.array(th), r=np.array(r), l=np.array(l), ang=np.array(ang))
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    m_step = {"omo": 256, "bob": 256, "qq-su": 256, "qcp-su": 256, "qbb": 128}
+    t_traj = {"omo": 300, "bob": 200, "qq-su": 200, "qcp-su": 200, "qbb": 150}
+    for i, name in enumerate(ENVS):
+        tag = name.replace("-", "_")
+        np.savez_compressed(os.path.join(OUT, f"step_{tag}.npz"), **gen_step_cases(name, m_step[name], 100 + i))
+        np.savez_compressed(os.path.join(OUT, f"traj_{tag}.npz"), **gen_traj(name, 8, t_traj[name], 200 + i))
+        np.savez_compressed(os.path.join(OUT, f"reset_{tag}.npz"), **gen_reset(name, 16, 300 + i))
+        print("wrote", name, flush=True)
+    np.savez_compressed(os.path.join(OUT, "cfg1_omo_500.npz"), **gen_cfg1())
+    np.savez_compressed(os.path.join(OUT, "qbb_ik.npz"), **gen_ik())
+    with open(os.path.join(OUT, "randomizers.json"), "w") as fh:
+        json.dump(gen_randomizer_tables(), fh, indent=1, sort_keys=True)
+    # seed KAT straight from the reference function (table also in Pyrado/tests/test_set_seed.py:35-54)
+    seeds = [[b, s, ss, pyrado.set_seed(b, s, ss)] for b in (0, 1, 7, 1001) for s in (None, 0, 1, 5) for ss in
+             (None, 0, 1, 255)]
+    with open(os.path.join(OUT, "set_seed.json"), "w") as fh:
+        json.dump(seeds, fh)
+    print("done")
+
+
+if __name__ == "__main__":
+    main()
