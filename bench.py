@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""
+bench.py -- env-steps/sec of the MI355X-native stepper on BASELINE.json's metric:
+"env-steps/sec whole node, 65 536 QQubeSwingUpSim envs, random policy".
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one pass of the hot path over the batch: every one of the 65 536 environments of a rank advances by one
+SimPyEnv.step (reward -> clip -> dead zone -> integrate -> done -> observe), finished lanes are auto-reset in the same
+kernel, the action comes from the on-device uniform random policy (DummyPolicy).  State, constants and actions are
+resident in HBM when the timed region starts.  Each rank owns 65 536 envs on its own GPU (weak scaling, the batch
+shards embarrassingly); the only collective is an RCCL all-gather of completed-episode return statistics at the end.
+
+Modes (--mode):
+  fused  (default) vs_step_random: `--chunk` env steps per launch, state in registers, obs/act/rew/done of EVERY step
+                   streamed to the trajectory buffers (record=1) -- what a rollout sampler needs.
+  step             one vs_step launch per env step, actions drawn by torch.rand on the GPU each step (policy in the loop).
+
+The JSON line also carries the roofline of the dominant kernel (HIP-event timed on the kernel's stream) and the CPU
+baseline (the oracle's NumPy port timed on this box's host cores, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# ALGORITHMIC bytes per env-step, fp32 SoA:
+#   single-step kernel: 4*[(S+A+P+H+1) read + (S+H+O+1+1) written] + 1 done byte
+#   fused rollout kernel with record: per step only the records leave the chip: 4*(O + A + 1) + 1; state/constants
+#   are read and written once per launch (amortised over `chunk` steps and added below)
+DIMS = {"omo": dict(S=2, A=1, O=2, P=3, H=0), "bob": dict(S=4, A=1, O=4, P=8, H=0), "qq-su": dict(S=4, A=1, O=6, P=11, H=0),
+        "qcp-su": dict(S=4, A=1, O=5, P=17, H=1), "qbb": dict(S=8, A=2, O=8, P=20, H=2)}
+ENV_KW = {"omo": dict(dt=0.02, max_steps=300), "bob": dict(dt=0.01, max_steps=500), "qq-su": dict(dt=0.004, max_steps=4000),
+          "qcp-su": dict(dt=0.002, max_steps=8000), "qbb": dict(dt=0.01, max_steps=500)}
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def bytes_single_step(d):
+    return 4 * ((d["S"] + d["A"] + d["P"] + d["H"] + 1) + (d["S"] + d["H"] + d["O"] + 1 + 1)) + 1
+
+
+def bytes_fused_step(d, chunk, record):
+    per_launch = 4 * ((d["S"] + d["P"] + d["H"] + 1) + (d["S"] + d["H"] + d["O"] + 1 + 1)) + 1  # state/consts in+out once
+    per_step = (4 * (d["O"] + d["A"] + 1) + 1) if record else 0
+    return per_step + per_launch / chunk
+
+
+def cpu_baseline(env_name, n_envs, budget_s=12.0):
+    """The oracle (NumPy port of the reference algorithm, fp64, vectorised over envs) on the host cores of this box."""
+    from oracle import cpu_ref
+
+    kw = ENV_KW[env_name]
+    ref = cpu_ref.make_ref(env_name, **kw)
+    rng = np.random.default_rng(0)
+    params = ref.nominal_params(n_envs)
+    lo, hi = ref.init_bounds(params) if env_name != "bob" else ref.init_bounds(params, 0)
+    state = rng.uniform(lo, hi)
+    if env_name == "qbb":
+        state = ref.state_from_init(ref.polar_to_init(state))
+    hidden = np.zeros((n_envs, ref.H))
+    _, _, alo, ahi = ref.bounds(params)
+    steps = np.zeros(n_envs, dtype=np.int64)
+    t0 = time.perf_counter()
+    done_steps = 0
+    while True:
+        act = rng.uniform(alo, ahi)
+        out = ref.step(state, hidden, act, params, steps)
+        state, hidden, steps = out["state"], out["hidden"], out["curr_step"]
+        d = out["done"]
+        if d.any():  # auto-reset, as on the device
+            fresh = rng.uniform(lo, hi)
+            if env_name == "qbb":
+                fresh = ref.state_from_init(ref.polar_to_init(fresh))
+            state[d] = fresh[d]
+            hidden[d] = 0
+            steps[d] = 0
+        done_steps += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    el = time.perf_counter() - t0
+    vec = n_envs * done_steps / el
+    # scalar mode: one env object stepped in a Python loop (how the reference itself is driven, minus its deepcopy)
+    p1, s1, h1, st1 = params[:1], state[:1].copy(), hidden[:1].copy(), steps[:1].copy()
+    t0 = time.perf_counter()
+    k = 0
+    while time.perf_counter() - t0 < 3.0:
+        o = ref.step(s1, h1, rng.uniform(alo[:1], ahi[:1]), p1, st1)
+        s1, h1, st1 = o["state"], o["hidden"], o["curr_step"]
+        if o["done"][0]:
+            s1, st1 = rng.uniform(lo[:1], hi[:1]) if env_name != "qbb" else s1 * 0, st1 * 0
+        k += 1
+    scalar = k / (time.perf_counter() - t0)
+    return dict(value=vec, unit="env-steps/s", cores=1, kind="port",
+                sample=f"oracle/cpu_ref.py (NumPy fp64, vectorised over {n_envs} envs, 1 thread), {done_steps} batch steps "
+                       f"in {el:.1f} s incl. auto-reset; scalar N=1 loop: {scalar:.0f} env-steps/s; "
+                       f"reference Pyrado itself: 2.1-2.6e3 env-steps/s/core (BASELINE.md, measured in the build container)",
+                scalar_value=scalar, host_cores=os.cpu_count())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
+    ap.add_argument("--env", default="qq-su", choices=sorted(DIMS))
+    ap.add_argument("--mode", default="fused", choices=["fused", "step"])
+    ap.add_argument("--chunk", type=int, default=100, help="env steps per launch in fused mode")
+    ap.add_argument("--record", type=int, default=1)
+    ap.add_argument("--per-env-params", type=int, default=1, help="1: per-env constants [K][N] (DR-capable), 0: broadcast")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--seed", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    import simurlacra_amd as vs
+    from simurlacra_amd import _lib as L
+
+    kw = ENV_KW[args.env]
+    d = DIMS[args.env]
+    n = args.envs
+    env = vs.VecSimEnv(args.env, n, device=local_rank, **kw)
+    if args.per_env_params:
+        env.set_params(np.tile(vs.nominal_params(args.env), (n, 1)))
+    env.set_auto_reset(True, seed=args.seed * 1000 + rank)
+    env.reset(seed=args.seed * 7919 + rank)  # per-rank Philox stream
+    chunk = max(1, min(args.chunk, args.steps))
+    n_launch = (args.steps + chunk - 1) // chunk
+    steps = n_launch * chunk if args.mode == "fused" else args.steps
+    _, _, alo, ahi = (None, None, None, None)
+    act_hi = {"omo": 30.0, "bob": 29.43, "qq-su": 4.5, "qcp-su": 6.0, "qbb": 3.0}[args.env]
+
+    def run(k_steps):
+        if args.mode == "fused":
+            for _ in range((k_steps + chunk - 1) // chunk):
+                env.step_random(chunk, seed=args.seed + rank, record=bool(args.record))
+        else:
+            for _ in range(k_steps):
+                act = (torch.rand(n, d["A"], device=f"cuda:{local_rank}") * 2 - 1) * act_hi
+                env.step(act)
+
+    if args.mode == "step":
+        env.use_stream(torch.cuda.current_stream().cuda_stream)
+    run(max(args.warmup, 1))
+    env.sync()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(steps)
+    env.sync()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    # gather completed-episode return statistics over RCCL (the only collective of this path)
+    r, ln, ix = env.episodes()
+    stats = torch.tensor([float(r.sum()), float(len(r)), float(ln.sum())], device=f"cuda:{local_rank}", dtype=torch.float64)
+    el_t = torch.tensor([el], device=f"cuda:{local_rank}", dtype=torch.float64)
+    if dist:
+        allstats = [torch.zeros_like(stats) for _ in range(world)]
+        dist.all_gather(allstats, stats)
+        dist.all_reduce(el_t, op=dist.ReduceOp.MAX)
+        stats = torch.stack(allstats).sum(dim=0)
+    el = float(el_t.item())
+    errs = env.error_count()
+
+    if rank == 0:
+        total_env_steps = float(n) * steps * world
+        value = total_env_steps / el
+        # roofline of the dominant kernel: HIP events on the kernel's own stream
+        if args.mode == "fused":
+            ms = env.time_step_kernel(iters=20, k_steps=chunk, record=bool(args.record))
+            b_per = bytes_fused_step(d, chunk, bool(args.record))
+            units = n * chunk
+            kname = "k_rollout"
+        else:
+            act = (torch.rand(n, d["A"], device=f"cuda:{local_rank}") * 2 - 1) * act_hi
+            torch.cuda.synchronize()
+            ms = env.time_step_kernel(iters=200, actions=act)
+            b_per = bytes_single_step(d)
+            units = n
+            kname = "k_step"
+        achieved = b_per * units / (ms * 1e-3) / 1e9
+        out = {
+            "metric": "env-steps/sec whole node, 65 536 QQubeSwingUpSim envs, random policy",
+            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
+            "ms_per_step": el / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.env} x {n} envs per GPU, dt {kw['dt']}, max_steps {kw['max_steps']}, uniform random "
+                                   f"policy on device, auto-reset, mode={args.mode}"
+                                   + (f", {chunk} steps/launch, record={args.record}" if args.mode == "fused" else "")
+                                   + (", per-env constants" if args.per_env_params else ", broadcast constants"),
+                       "envs_per_gpu": n, "env": args.env, "mode": args.mode, "chunk": chunk, "record": args.record,
+                       "parallelism": f"env-shard x{world}"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": kname,
+                         "kernel_ms": ms, "alg_bytes_per_env_step": b_per, "env_steps_per_launch": units},
+            "episodes": {"completed": int(stats[1].item()), "mean_return": float(stats[0].item() / max(stats[1].item(), 1)),
+                         "mean_length": float(stats[2].item() / max(stats[1].item(), 1))},
+            "nan_flags": errs,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args.env, min(n, 65536))
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    env.close()
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,185 @@
+/*
+ * vecsim.h -- C-ABI of libvecsim: an MI355X (gfx950) native, batched, device-resident stepper for Pyrado's
+ * pure-Python simulated robots (SimPyEnv subclasses).
+ *
+ * The reference (swami1995/SimuRLacra, Pyrado) has no FFI for this path: the boundary is the Python duck type
+ * Env/SimEnv consumed by rollout(), the env wrappers and the samplers.  Each entry point below is the batched
+ * (N environments, one per wavefront lane) replacement of one reference method; the host-side mirror of the Python
+ * surface lives in simurlacra_amd/ and calls these through ctypes (see INTEGRATION.md for the stub).
+ * `P/` = Pyrado/pyrado/ in the reference tree.
+ *
+ * Conventions
+ *   - every function returns an int status: 0 = VS_OK, < 0 = error (vs_last_error() gives the text); nothing throws;
+ *   - the library owns all device buffers; callers get raw device pointers (vs_get) and never free them;
+ *   - one handle <-> one HIP device + one stream; a handle is not re-entrant, independent handles are thread-safe;
+ *   - all per-env arrays are fp32 struct-of-arrays [dim][ld] with row pitch ld = vs_ld() >= n_envs (rows 256-B
+ *     aligned); done/err flags are uint8 [ld], step counters int32 [ld];
+ *   - pointers passed IN (params, init states, actions, masks) may be host or device memory (detected with
+ *     hipPointerGetAttributes) unless stated otherwise; SoA inputs use row pitch n_envs when they come from the
+ *     host and an explicit pitch argument when they are device pointers.
+ */
+#ifndef VECSIM_H
+#define VECSIM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VS_OK 0
+#define VS_ERR_ARG (-1)     /* bad argument (shape, enum, null) -- pyrado.ShapeErr / ValueErr / TypeErr on the host side */
+#define VS_ERR_HIP (-2)     /* a HIP runtime call failed (no device, OOM, launch error) */
+#define VS_ERR_STATE (-3)   /* call order / handle state */
+#define VS_ERR_NAN (-4)     /* NaN seen in an action or a state: BoxSpace.contains raises ValueErr, P/spaces/box.py:142-146 */
+
+/* environment families (the `name` attribute of the reference classes) */
+enum vs_env_type {
+    VS_ENV_OMO = 0,    /* "omo"    OneMassOscillatorSim  P/environments/pysim/one_mass_oscillator.py:49-121 */
+    VS_ENV_BOB = 1,    /* "bob"    BallOnBeamSim         P/environments/pysim/ball_on_beam.py:41-136 */
+    VS_ENV_QQ_SU = 2,  /* "qq-su"  QQubeSwingUpSim       P/environments/pysim/quanser_qube.py:41-188 */
+    VS_ENV_QCP_SU = 3, /* "qcp-su" QCartPoleSwingUpSim   P/environments/pysim/quanser_cartpole.py:45-230,507-587 */
+    VS_ENV_QBB = 4,    /* "qbb"    QBallBalancerSim      P/environments/pysim/quanser_ball_balancer.py:49-337 */
+    VS_ENV_COUNT = 5
+};
+
+/* buffers addressable through vs_get / vs_copy_to_host / vs_copy_from_host */
+enum vs_buffer {
+    VS_STATE = 0,      /* f32 [S][ld]  Env.state                                  P/environments/base.py:65 */
+    VS_OBS = 1,        /* f32 [O][ld]  observe(state) after the last step/reset   P/environments/pysim/base.py:241 */
+    VS_REW = 2,        /* f32 [ld]     reward of the last step (incl. final reward) base.py:220,237-239 */
+    VS_DONE = 3,       /* u8  [ld]     done flag of the last step                 base.py:232-235 */
+    VS_HIDDEN = 4,     /* f32 [H][ld]  qcp: _th_ddot, qbb: plate_angs             quanser_cartpole.py:74, quanser_ball_balancer.py:83 */
+    VS_STEPCOUNT = 5,  /* i32 [ld]     Env.curr_step */
+    VS_ERRFLAG = 6,    /* u8  [ld]     sticky: NaN seen in act/state (reference raises pyrado.ValueErr) */
+    VS_RETURNS = 7,    /* f32 [ld]     undiscounted return of the running episode */
+    VS_PARAMS = 8,     /* f32 [P][ld]  domain parameters, order = get_nominal_domain_param() */
+    VS_CONSTS = 9,     /* f32 [K][ld]  derived constants (_calc_constants, bounds, c_max); layout in DESIGN.md */
+    VS_EP_RETURNS = 10,/* f32 [ep_cap] completed-episode returns, append order (ring) */
+    VS_EP_LENGTHS = 11,/* i32 [ep_cap] completed-episode lengths */
+    VS_EP_ENVIDX = 12, /* i32 [ep_cap] env index of each completed episode */
+    VS_EP_COUNT = 13,  /* u32 [1]      number of episodes appended since vs_clear_episodes */
+    VS_TRAJ_OBS = 14,  /* f32 [T][O][ld] recorded by vs_step_random(record=1): obs BEFORE each step */
+    VS_TRAJ_ACT = 15,  /* f32 [T][A][ld] raw (unclipped) actions */
+    VS_TRAJ_REW = 16,  /* f32 [T][ld] */
+    VS_TRAJ_DONE = 17, /* u8  [T][ld] */
+    VS_FAILED = 18,    /* u8  [ld]     Task.has_failed(state) of the last step   P/tasks/base.py:159-167 */
+    VS_BUFFER_COUNT = 19
+};
+
+/* vs_task_cfg.flags */
+#define VS_FLAG_SIMPLE_DYNAMICS 1 /* qcp / qbb ctor arg simple_dynamics=True */
+#define VS_FLAG_LONG_POLE 2       /* qcp ctor arg long=True (changes the nominal pole only) */
+
+/* Task / ctor configuration. Zero-initialise and set `use_defaults = 1` to get the reference defaults
+ * (_create_task of each env).  Q and R are diagonal (all reference defaults are). */
+typedef struct vs_task_cfg {
+    int32_t use_defaults; /* 1: ignore state_des/q_diag/r_diag below */
+    int32_t flags;        /* VS_FLAG_* */
+    int32_t wild_init;    /* qcp: 0 = 'True' (default), 1 = 'False', 2 = anything else   quanser_cartpole.py:552-560 */
+    int32_t reserved;
+    float state_des[8];   /* task_args['state_des'] */
+    float q_diag[8];      /* diag(task_args['Q']) */
+    float r_diag[2];      /* diag(task_args['R']) */
+} vs_task_cfg;
+
+/* One randomised domain parameter: DomainParam.sample = distr.sample -> clamp(clip_lo, clip_up)
+ * (P/domain_randomization/domain_parameter.py:104-203) */
+#define VS_DP_NORMAL 0  /* NormalDomainParam(mean, std)       spread = std */
+#define VS_DP_UNIFORM 1 /* UniformDomainParam(mean, halfspan) spread = halfspan */
+typedef struct vs_dp_spec {
+    int32_t param_index; /* row in VS_PARAMS */
+    int32_t kind;        /* VS_DP_* */
+    float mean;
+    float spread;
+    float clip_lo;       /* -INFINITY for none */
+    float clip_up;       /* +INFINITY for none */
+} vs_dp_spec;
+
+typedef struct vs_env* vs_handle;
+
+/* ---- static information (no GPU needed) ---- */
+
+/* widths of an env family: state, action, observation, #domain params, hidden state, init-space element, #constants */
+int vs_env_dims(int env_type, int* S, int* A, int* O, int* P, int* H, int* I, int* K);
+/* the `name` class attribute ("qq-su", ...), NULL for a bad type */
+const char* vs_env_name(int env_type);
+/* i-th domain parameter name in get_nominal_domain_param() order, NULL when out of range */
+const char* vs_param_name(int env_type, int i);
+/* nominal domain parameters (get_nominal_domain_param; qcp honours VS_FLAG_LONG_POLE); out has P floats */
+int vs_nominal_params(int env_type, int flags, float* out);
+/* library / ABI version */
+int vs_version(void);
+
+/* ---- lifetime ---- */
+
+/* Replaces the env constructor (SimPyEnv.__init__, P/environments/pysim/base.py:46-80) for n_envs instances:
+ * nominal domain params, derived constants, spaces and task.  max_steps <= 0 means pyrado.inf.  cfg may be NULL. */
+int vs_create(int env_type, int64_t n_envs, double dt, int64_t max_steps, int device_id, const vs_task_cfg* cfg,
+              vs_handle* out);
+int vs_destroy(vs_handle h);
+/* run on this hipStream_t (e.g. torch's current stream) instead of the handle's own stream; NULL restores it */
+int vs_set_stream(vs_handle h, void* hip_stream);
+int vs_sync(vs_handle h);
+int64_t vs_n_envs(vs_handle h);
+int64_t vs_ld(vs_handle h);
+const char* vs_last_error(vs_handle h); /* h may be NULL: last error of a failed vs_create on this thread */
+
+/* ---- domain parameters: the `domain_param` setter (P/environments/pysim/base.py:112-124) ---- */
+
+/* params_soa: f32 [P][pitch]; pitch = n_envs for host memory. mask (u8 [n_envs], may be NULL = all) selects the envs.
+ * Recomputes _calc_constants, the spaces' bounds and the reward scale c_max for the selected envs. */
+int vs_set_params(vs_handle h, const float* params_soa, int64_t pitch, const uint8_t* mask);
+/* the same parameter vector (P floats, host) for every env; enables the broadcast-constant kernels */
+int vs_set_params_uniform(vs_handle h, const float* params);
+/* DomainRandomizer.randomize + get_params on device (P/domain_randomization/domain_randomizer.py:123-227):
+ * Normal/Uniform draws (Philox4x32-10 keyed by seed), clipped; parameters without a spec keep their value. */
+int vs_sample_params(vs_handle h, const vs_dp_spec* specs, int n_specs, uint64_t seed, const uint8_t* mask);
+/* DomainRandWrapperLive (P/environment_wrappers/domain_randomization.py:135-148): remember specs and redraw the
+ * parameters of an env at each of its resets (vs_reset without explicit params, and auto-reset). n_specs = 0 disables. */
+int vs_set_randomizer(vs_handle h, const vs_dp_spec* specs, int n_specs);
+
+/* ---- reset: SimPyEnv.reset (P/environments/pysim/base.py:166-203) ---- */
+
+/* init_state: NULL -> sample the env's init space on device (init_space.sample_uniform, P/spaces/box.py:169-178,
+ * polar.py:108-113, compound.py:84-87); else f32 [I or S][pitch] (init_is_full_state selects which, base.py:184-193).
+ * mask as above.  seed keys the Philox stream used for sampling (and for live domain randomisation). */
+int vs_reset(vs_handle h, const float* init_state, int64_t pitch, int init_is_full_state, const uint8_t* mask,
+             uint64_t seed);
+/* when on, a lane whose episode ended is reset inside the same step kernel (fresh init state, redrawn params when a
+ * randomizer is set); VS_OBS then holds the first observation of the new episode, VS_REW/VS_DONE the finished step */
+int vs_set_auto_reset(vs_handle h, int on, uint64_t seed);
+
+/* ---- step: SimPyEnv.step (P/environments/pysim/base.py:217-241), fused in one kernel ---- */
+
+/* actions: device f32, element (env i, dim j) at actions[i * env_stride + j * dim_stride]
+ * ([A][ld] SoA: env_stride 1, dim_stride ld;  [N][A] row-major policy output: env_stride A, dim_stride 1) */
+int vs_step(vs_handle h, const float* actions, int64_t env_stride, int64_t dim_stride);
+/* rollout() with DummyPolicy (P/sampling/rollout.py:185-239, P/policies/feed_forward/dummy.py:77-84):
+ * k_steps env steps in ONE launch with on-device uniform actions in act_space, state kept in registers.
+ * record != 0 streams obs/act/rew/done of every step into the VS_TRAJ_* buffers (k_steps <= vs_traj_capacity). */
+int vs_step_random(vs_handle h, uint64_t seed, int k_steps, int record);
+int vs_set_traj_capacity(vs_handle h, int t_max);
+int vs_clear_episodes(vs_handle h);
+
+/* ---- data access ---- */
+
+void* vs_get(vs_handle h, int which);                       /* device pointer, NULL on error */
+int vs_copy_to_host(vs_handle h, int which, void* dst);     /* whole buffer, pitch ld (synchronises the stream) */
+int vs_copy_from_host(vs_handle h, int which, const void* src); /* VS_STATE / VS_HIDDEN / VS_STEPCOUNT: `state` setter */
+/* number of lanes with the sticky error flag set (synchronises); the host shim raises pyrado.ValueErr when > 0 */
+int64_t vs_error_count(vs_handle h);
+
+/* ---- measurement ---- */
+
+/* average device time [ms] of the step kernel over `iters` launches, measured with hipEvents on the handle's stream
+ * (mode 0: vs_step with the given device actions, mode 1: vs_step_random(k_steps, record)) */
+int vs_time_step_kernel(vs_handle h, int mode, const float* actions, int64_t env_stride, int64_t dim_stride,
+                        int k_steps, int record, int iters, float* avg_ms);
+/* streaming copy kernel (float4) over `bytes` of device memory: achieved GB/s (in-repo HBM reference point) */
+int vs_membw_probe(int device_id, int64_t bytes, int iters, float* gbps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VECSIM_H */

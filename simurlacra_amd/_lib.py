@@ -1,0 +1,86 @@
+"""ctypes binding of libvecsim (include/vecsim.h). Fails loudly when the HIP library is missing: no CPU fallback."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libvecsim.so")
+
+VS_OK, VS_ERR_ARG, VS_ERR_HIP, VS_ERR_STATE, VS_ERR_NAN = 0, -1, -2, -3, -4
+ENV_TYPES = {"omo": 0, "bob": 1, "qq-su": 2, "qcp-su": 3, "qbb": 4}
+(VS_STATE, VS_OBS, VS_REW, VS_DONE, VS_HIDDEN, VS_STEPCOUNT, VS_ERRFLAG, VS_RETURNS, VS_PARAMS, VS_CONSTS,
+ VS_EP_RETURNS, VS_EP_LENGTHS, VS_EP_ENVIDX, VS_EP_COUNT, VS_TRAJ_OBS, VS_TRAJ_ACT, VS_TRAJ_REW, VS_TRAJ_DONE,
+ VS_FAILED) = range(19)
+VS_FLAG_SIMPLE_DYNAMICS, VS_FLAG_LONG_POLE = 1, 2
+VS_DP_NORMAL, VS_DP_UNIFORM = 0, 1
+
+
+class TaskCfg(C.Structure):
+    _fields_ = [("use_defaults", C.c_int32), ("flags", C.c_int32), ("wild_init", C.c_int32), ("reserved", C.c_int32),
+                ("state_des", C.c_float * 8), ("q_diag", C.c_float * 8), ("r_diag", C.c_float * 2)]
+
+
+class DpSpec(C.Structure):
+    _fields_ = [("param_index", C.c_int32), ("kind", C.c_int32), ("mean", C.c_float), ("spread", C.c_float),
+                ("clip_lo", C.c_float), ("clip_up", C.c_float)]
+
+
+_P = C.c_void_p
+_SIGNATURES = {
+    "vs_version": (C.c_int, []),
+    "vs_env_dims": (C.c_int, [C.c_int] + [C.POINTER(C.c_int)] * 7),
+    "vs_env_name": (C.c_char_p, [C.c_int]),
+    "vs_param_name": (C.c_char_p, [C.c_int, C.c_int]),
+    "vs_nominal_params": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_float)]),
+    "vs_create": (C.c_int, [C.c_int, C.c_int64, C.c_double, C.c_int64, C.c_int, C.POINTER(TaskCfg), C.POINTER(_P)]),
+    "vs_destroy": (C.c_int, [_P]),
+    "vs_set_stream": (C.c_int, [_P, _P]),
+    "vs_sync": (C.c_int, [_P]),
+    "vs_n_envs": (C.c_int64, [_P]),
+    "vs_ld": (C.c_int64, [_P]),
+    "vs_last_error": (C.c_char_p, [_P]),
+    "vs_set_params": (C.c_int, [_P, _P, C.c_int64, _P]),
+    "vs_set_params_uniform": (C.c_int, [_P, C.POINTER(C.c_float)]),
+    "vs_sample_params": (C.c_int, [_P, C.POINTER(DpSpec), C.c_int, C.c_uint64, _P]),
+    "vs_set_randomizer": (C.c_int, [_P, C.POINTER(DpSpec), C.c_int]),
+    "vs_reset": (C.c_int, [_P, _P, C.c_int64, C.c_int, _P, C.c_uint64]),
+    "vs_set_auto_reset": (C.c_int, [_P, C.c_int, C.c_uint64]),
+    "vs_step": (C.c_int, [_P, _P, C.c_int64, C.c_int64]),
+    "vs_step_random": (C.c_int, [_P, C.c_uint64, C.c_int, C.c_int]),
+    "vs_set_traj_capacity": (C.c_int, [_P, C.c_int]),
+    "vs_clear_episodes": (C.c_int, [_P]),
+    "vs_get": (_P, [_P, C.c_int]),
+    "vs_copy_to_host": (C.c_int, [_P, C.c_int, _P]),
+    "vs_copy_from_host": (C.c_int, [_P, C.c_int, _P]),
+    "vs_error_count": (C.c_int64, [_P]),
+    "vs_time_step_kernel": (C.c_int, [_P, C.c_int, _P, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int,
+                                      C.POINTER(C.c_float)]),
+    "vs_membw_probe": (C.c_int, [C.c_int, C.c_int64, C.c_int, C.POINTER(C.c_float)]),
+}
+
+_lib = None
+
+
+class VecSimLibraryError(ImportError):
+    pass
+
+
+def load():
+    """Load libvecsim.so (built in-tree by simurlacra_amd/csrc/build.py). Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VecSimLibraryError(
+            f"{LIB_PATH} is missing. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"(hipcc --offload-arch=gfx950). simurlacra_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)

@@ -1,0 +1,1029 @@
+// vecsim.hip -- libvecsim: HIP kernels (gfx950 / CDNA4) + the C-ABI of include/vecsim.h.
+//
+// One environment per wavefront lane, all per-env data fp32 struct-of-arrays [dim][ld] so that every load/store of a
+// wave is one contiguous 256-B segment.  The step of SimPyEnv (reward -> clip -> dead zone -> integrate -> done ->
+// final reward -> observe, P/environments/pysim/base.py:217-241) is ONE kernel; there is no CPU fallback anywhere:
+// every entry point either runs on the GPU or returns an error.
+#include <hip/hip_runtime.h>
+
+#include <climits>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/vecsim.h"
+#include "vecsim_envs.h"
+
+namespace vs {
+
+constexpr int BLOCK = 256;
+
+struct DrSpecs {
+    int n;
+    vs_dp_spec s[MAXP];
+};
+
+// device pointers of one handle, passed to kernels by value
+struct Dev {
+    float *state, *hidden, *obs, *rew, *ret, *consts, *params, *consts_uni;
+    uint8_t *done, *failed, *err, *yielded;
+    int* step;
+    float* ep_ret;
+    int *ep_len, *ep_env;
+    unsigned* ep_count;
+    unsigned ep_cap;
+    float *traj_obs, *traj_act, *traj_rew;
+    uint8_t* traj_done;
+    int n, ld;
+};
+
+// ---------------------------------------------------------------------------------------------------- reward / step
+// DesStateTask.step_rew / RadiallySymmDesStateTask.step_rew + the three reward functions
+// (P/tasks/desired_state.py:107-110,146-155; P/tasks/reward_functions.py:212-221,237-244,276-282)
+template <class E>
+__device__ __forceinline__ float step_reward(const Task& T, const float* c, const float* s, const float* a_raw) {
+    float cost = 0.f;
+#pragma unroll
+    for (int j = 0; j < E::S; ++j) {
+        float e = T.des[j] - s[j];
+        if (E::RADIAL >= 0) {
+            if (j == E::RADIAL) e = fmod_2pi(e);
+            e = fold_pi(e);  // all dims (Q4)
+        }
+        cost += e * (T.qd[j] * e);
+    }
+    float ca = 0.f;
+#pragma unroll
+    for (int j = 0; j < E::A; ++j) ca += a_raw[j] * (T.rd[j] * a_raw[j]);  // err_a = -act
+    cost += ca;
+    if (E::REW == REW_QUADR) return -cost;
+    if (E::REW == REW_EXP) return expf(-cost);
+    return expf(-c[E::CMAX >= 0 ? E::CMAX : 0] * cost);
+}
+
+struct StepOut {
+    float rew;
+    bool done, failed, err;
+};
+
+// SimPyEnv.step for one lane (P/environments/pysim/base.py:217-241); s, h, step, yielded are updated in place
+template <class E>
+__device__ __forceinline__ StepOut step_one(const Task& T, const float* c, float* s, float* h, const float* a_raw,
+                                            int& step, bool& yielded) {
+    StepOut o;
+    o.rew = step_reward<E>(T, c, s, a_raw);  // pre-step state, unclipped action (Q3)
+    float alo[E::A], ahi[E::A], a[E::A];
+    E::act_bounds(c, alo, ahi);
+    o.err = false;
+#pragma unroll
+    for (int j = 0; j < E::A; ++j) {
+        o.err |= isnan(a_raw[j]);
+        a[j] = fminf(fmaxf(a_raw[j], alo[j]), ahi[j]);  // limit_act -> BoxSpace.project_to (box.py:180-184)
+        if (isnan(a_raw[j])) a[j] = a_raw[j];           // np.clip propagates NaN (fminf/fmaxf would drop it)
+    }
+    E::dynamics(T, c, s, h, a);
+    step += 1;
+    float slo[E::S], shi[E::S];
+    E::state_bounds(c, slo, shi);
+    o.failed = false;
+#pragma unroll
+    for (int j = 0; j < E::S; ++j) {
+        o.err |= isnan(s[j]);
+        o.failed |= (s[j] < slo[j]) | (s[j] > shi[j]);  // not state_space.contains(s') (Q9, Q10)
+    }
+    o.done = o.failed | (step >= T.max_steps);
+    if (E::HAS_FINAL) {
+        // FinalRewTask(always_negative): -factor on failure, paid once per episode (final_reward.py:130-135,165-174)
+        if (o.done && !yielded) {
+            if (o.failed) o.rew += -1000.0f;
+            yielded = true;
+        }
+    }
+    return o;
+}
+
+template <class E, bool UNI>
+__device__ __forceinline__ void load_consts(const Dev& d, int i, float* c, int count) {
+    if (UNI) {
+#pragma unroll
+        for (int k = 0; k < E::K; ++k)
+            if (k < count) c[k] = d.consts_uni[k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < E::K; ++k)
+            if (k < count) c[k] = d.consts[(size_t)k * d.ld + i];
+    }
+}
+
+// DomainRandomizer.randomize for one lane (domain_parameter.py:104-132): draw -> clamp; writes the raw params
+template <class E>
+__device__ __forceinline__ void draw_params(const DrSpecs& dr, Rng& g, float* p) {
+    for (int q = 0; q < dr.n; ++q) {
+        const vs_dp_spec& sp = dr.s[q];
+        float v = sp.kind == VS_DP_NORMAL ? sp.mean + sp.spread * g.normal()
+                                          : g.uniform(sp.mean - sp.spread, sp.mean + sp.spread);
+        v = fminf(fmaxf(v, sp.clip_lo), sp.clip_up);
+#pragma unroll
+        for (int k = 0; k < E::P; ++k)
+            if (k == sp.param_index) p[k] = v;
+    }
+}
+
+// SimPyEnv.reset for one lane with a sampled init state (P/environments/pysim/base.py:166-203), incl. the
+// DomainRandWrapperLive redraw (environment_wrappers/domain_randomization.py:141-148) when dr.n > 0
+template <class E>
+__device__ __forceinline__ void reset_lane_sampled(const Task& T, const Dev& d, const DrSpecs& dr, int i, uint64_t seed,
+                                                   uint64_t epoch, float* c, float* s, float* h) {
+    if (dr.n > 0) {
+        float p[E::P];
+#pragma unroll
+        for (int k = 0; k < E::P; ++k) p[k] = d.params[(size_t)k * d.ld + i];
+        Rng gp(seed, (uint32_t)i, RNG_PARAM, epoch);
+        draw_params<E>(dr, gp, p);
+        E::calc_consts(T, p, c);
+#pragma unroll
+        for (int k = 0; k < E::P; ++k) d.params[(size_t)k * d.ld + i] = p[k];
+#pragma unroll
+        for (int k = 0; k < E::K; ++k) d.consts[(size_t)k * d.ld + i] = c[k];
+    }
+    Rng g(seed, (uint32_t)i, RNG_INIT, epoch);
+    float init[E::I];
+    E::sample_init(T, c, g, init);
+    E::state_from_init(init, s);
+    E::init_hidden(T, c, nullptr, s, h, false);
+}
+
+// completed-episode append with a wavefront ballot: one atomic per wave, lanes ranked by popcount of the lower mask
+__device__ __forceinline__ void append_episode(const Dev& d, bool fin, int i, float ret, int len) {
+    unsigned long long m = __ballot(fin);
+    if (m == 0ull) return;
+    unsigned lane = __lane_id();
+    unsigned base = 0;
+    if (lane == (unsigned)(__ffsll((long long)m) - 1)) base = atomicAdd(d.ep_count, (unsigned)__popcll(m));
+    base = __shfl(base, __ffsll((long long)m) - 1);
+    if (fin) {
+        unsigned slot = (base + (unsigned)__popcll(m & ((1ull << lane) - 1ull))) % d.ep_cap;
+        d.ep_ret[slot] = ret;
+        d.ep_len[slot] = len;
+        d.ep_env[slot] = i;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------- step kernel
+// vs_step: one fused SimPyEnv.step per lane.  AR = auto-reset of finished lanes inside the same launch.
+template <class E, bool UNI, bool AR>
+__global__ __launch_bounds__(BLOCK) void k_step(Task T, Dev d, DrSpecs dr, const float* __restrict__ act,
+                                                long env_stride, long dim_stride, uint64_t seed, uint64_t epoch) {
+    int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= d.ld) return;
+    const size_t ld = d.ld;
+    float c[E::K], s[E::S], h[E::H > 0 ? E::H : 1], a[E::A];
+    load_consts<E, UNI>(d, i, c, E::KS);
+#pragma unroll
+    for (int j = 0; j < E::S; ++j) s[j] = d.state[j * ld + i];
+#pragma unroll
+    for (int j = 0; j < E::H; ++j) h[j] = d.hidden[j * ld + i];
+    bool valid = i < d.n;
+#pragma unroll
+    for (int j = 0; j < E::A; ++j) a[j] = valid ? act[(size_t)i * env_stride + (size_t)j * dim_stride] : 0.f;
+    int step = d.step[i];
+    bool yielded = E::HAS_FINAL ? d.yielded[i] != 0 : false;
+
+    StepOut o = step_one<E>(T, c, s, h, a, step, yielded);
+
+    float ret = d.ret[i] + o.rew;
+    d.rew[i] = o.rew;
+    d.done[i] = o.done;
+    d.failed[i] = o.failed;
+    if (o.err && valid) d.err[i] = 1;  // sticky, write-only
+
+    if (AR) {
+        bool fin = o.done && valid;
+        append_episode(d, fin, i, ret, step);
+        if (__ballot(fin) != 0ull) {  // wave-uniform skip: most waves have no finished lane
+            if (fin) {
+                if (UNI) load_consts<E, UNI>(d, i, c, E::K);
+                else {
+#pragma unroll
+                    for (int k = E::KS; k < E::K; ++k) c[k] = d.consts[(size_t)k * ld + i];
+                }
+                reset_lane_sampled<E>(T, d, dr, i, seed, epoch, c, s, h);
+                step = 0;
+                ret = 0.f;
+                yielded = false;
+            }
+        }
+    }
+    float ob[E::O];
+    E::observe(s, ob);
+#pragma unroll
+    for (int j = 0; j < E::S; ++j) d.state[j * ld + i] = s[j];
+#pragma unroll
+    for (int j = 0; j < E::H; ++j) d.hidden[j * ld + i] = h[j];
+#pragma unroll
+    for (int j = 0; j < E::O; ++j) d.obs[j * ld + i] = ob[j];
+    d.step[i] = step;
+    d.ret[i] = ret;
+    if (E::HAS_FINAL) d.yielded[i] = yielded;
+}
+
+// ---------------------------------------------------------------------------------------------------- rollout kernel
+// vs_step_random: rollout() with DummyPolicy (rollout.py:185-239, dummy.py:77-84) -- k env steps per launch, state,
+// hidden state and constants stay in registers; only the per-step records stream to HBM when REC.
+// Without auto-reset a finished lane freezes (rollout stops at done).
+template <class E, bool UNI, bool AR, bool REC>
+__global__ __launch_bounds__(BLOCK) void k_rollout(Task T, Dev d, DrSpecs dr, int k_steps, uint64_t seed,
+                                                   uint64_t epoch0) {
+    int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= d.ld) return;
+    const size_t ld = d.ld;
+    bool valid = i < d.n;
+    float c[E::K], s[E::S], h[E::H > 0 ? E::H : 1], a[E::A], ob[E::O];
+    load_consts<E, UNI>(d, i, c, E::K);
+#pragma unroll
+    for (int j = 0; j < E::S; ++j) s[j] = d.state[j * ld + i];
+#pragma unroll
+    for (int j = 0; j < E::H; ++j) h[j] = d.hidden[j * ld + i];
+    int step = d.step[i];
+    float ret = d.ret[i];
+    bool yielded = E::HAS_FINAL ? d.yielded[i] != 0 : false;
+    bool frozen = !AR && d.done[i] != 0;
+    float rew = d.rew[i];
+    bool done = d.done[i] != 0, failed = d.failed[i] != 0;
+    float alo[E::A], ahi[E::A];
+    E::observe(s, ob);
+
+    for (int t = 0; t < k_steps; ++t) {
+        E::act_bounds(c, alo, ahi);
+        Rng g(seed, (uint32_t)i, RNG_ACT, epoch0 + (uint64_t)t);
+#pragma unroll
+        for (int j = 0; j < E::A; ++j) a[j] = g.uniform(alo[j], ahi[j]);  // act_space.sample_uniform()
+        if (REC) {
+            size_t tb = (size_t)t;
+#pragma unroll
+            for (int j = 0; j < E::O; ++j) d.traj_obs[(tb * E::O + j) * ld + i] = ob[j];
+#pragma unroll
+            for (int j = 0; j < E::A; ++j) d.traj_act[(tb * E::A + j) * ld + i] = a[j];
+        }
+        if (!frozen) {
+            StepOut o = step_one<E>(T, c, s, h, a, step, yielded);
+            rew = o.rew;
+            done = o.done;
+            failed = o.failed;
+            ret += o.rew;
+            if (o.err && valid) d.err[i] = 1;
+        } else {
+            rew = 0.f;
+        }
+        if (REC) {
+            d.traj_rew[(size_t)t * ld + i] = rew;
+            d.traj_done[(size_t)t * ld + i] = done;
+        }
+        bool fin = done && valid && !frozen;
+        if (AR) {
+            append_episode(d, fin, i, ret, step);
+            if (__ballot(fin) != 0ull) {
+                if (fin) {
+                    reset_lane_sampled<E>(T, d, dr, i, seed, epoch0 + (uint64_t)t, c, s, h);
+                    step = 0;
+                    ret = 0.f;
+                    yielded = false;
+                }
+            }
+        } else {
+            append_episode(d, fin, i, ret, step);
+            frozen |= done;
+        }
+        E::observe(s, ob);
+    }
+#pragma unroll
+    for (int j = 0; j < E::S; ++j) d.state[j * ld + i] = s[j];
+#pragma unroll
+    for (int j = 0; j < E::H; ++j) d.hidden[j * ld + i] = h[j];
+#pragma unroll
+    for (int j = 0; j < E::O; ++j) d.obs[j * ld + i] = ob[j];
+    d.step[i] = step;
+    d.ret[i] = ret;
+    d.rew[i] = rew;
+    d.done[i] = done;
+    d.failed[i] = failed;
+    if (E::HAS_FINAL) d.yielded[i] = yielded;
+}
+
+// -------------------------------------------------------------------------------------------- params / reset kernels
+// domain_param setter (P/environments/pysim/base.py:112-124): _calc_constants + spaces + task.reset for masked lanes.
+// src == nullptr: recompute from the stored params; bcast: src is one [P] vector for every lane.
+template <class E>
+__global__ __launch_bounds__(BLOCK) void k_set_params(Task T, Dev d, const float* __restrict__ src, long pitch,
+                                                      int bcast, const uint8_t* __restrict__ mask) {
+    int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= d.ld) return;
+    if (mask && (i >= d.n || mask[i] == 0)) return;
+    int is = i < d.n ? i : d.n - 1;  // padding lanes mirror the last env (keeps them finite)
+    float p[E::P], c[E::K];
+#pragma unroll
+    for (int k = 0; k < E::P; ++k)
+        p[k] = src ? (bcast ? src[k] : src[(size_t)k * pitch + is]) : d.params[(size_t)k * d.ld + is];
+    E::calc_consts(T, p, c);
+#pragma unroll
+    for (int k = 0; k < E::P; ++k) d.params[(size_t)k * d.ld + i] = p[k];
+#pragma unroll
+    for (int k = 0; k < E::K; ++k) d.consts[(size_t)k * d.ld + i] = c[k];
+    if (bcast && i == 0) {
+#pragma unroll
+        for (int k = 0; k < E::K; ++k) d.consts_uni[k] = c[k];
+    }
+}
+
+template <class E>
+__global__ __launch_bounds__(BLOCK) void k_sample_params(Task T, Dev d, DrSpecs dr, uint64_t seed, uint64_t epoch,
+                                                         const uint8_t* __restrict__ mask) {
+    int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= d.n) return;
+    if (mask && mask[i] == 0) return;
+    float p[E::P], c[E::K];
+#pragma unroll
+    for (int k = 0; k < E::P; ++k) p[k] = d.params[(size_t)k * d.ld + i];
+    Rng g(seed, (uint32_t)i, RNG_PARAM, epoch);
+    draw_params<E>(dr, g, p);
+    E::calc_consts(T, p, c);
+#pragma unroll
+    for (int k = 0; k < E::P; ++k) d.params[(size_t)k * d.ld + i] = p[k];
+#pragma unroll
+    for (int k = 0; k < E::K; ++k) d.consts[(size_t)k * d.ld + i] = c[k];
+}
+
+// SimPyEnv.reset (P/environments/pysim/base.py:166-203) for masked lanes; init == nullptr samples the init space
+template <class E>
+__global__ __launch_bounds__(BLOCK) void k_reset(Task T, Dev d, DrSpecs dr, const float* __restrict__ init, long pitch,
+                                                 int full_state, const uint8_t* __restrict__ mask, uint64_t seed,
+                                                 uint64_t epoch) {
+    int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= d.ld) return;
+    bool valid = i < d.n;
+    if (mask && (!valid || mask[i] == 0)) return;
+    const size_t ld = d.ld;
+    float c[E::K], s[E::S], h[E::H > 0 ? E::H : 1], ob[E::O];
+    load_consts<E, false>(d, i, c, E::K);
+    if (init == nullptr || !valid) {
+        DrSpecs none;
+        none.n = 0;
+        reset_lane_sampled<E>(T, d, valid ? dr : none, i, seed, epoch, c, s, h);
+    } else {
+        if (dr.n > 0) {  // DomainRandWrapperLive.reset with an explicit init_state still redraws the params
+            float p[E::P];
+#pragma unroll
+            for (int k = 0; k < E::P; ++k) p[k] = d.params[(size_t)k * ld + i];
+            Rng gp(seed, (uint32_t)i, RNG_PARAM, epoch);
+            draw_params<E>(dr, gp, p);
+            E::calc_consts(T, p, c);
+#pragma unroll
+            for (int k = 0; k < E::P; ++k) d.params[(size_t)k * ld + i] = p[k];
+#pragma unroll
+            for (int k = 0; k < E::K; ++k) d.consts[(size_t)k * ld + i] = c[k];
+        }
+        if (full_state) {
+#pragma unroll
+            for (int j = 0; j < E::S; ++j) s[j] = init[(size_t)j * pitch + i];  // copied verbatim (base.py:184-188)
+        } else {
+            float in[E::I];
+#pragma unroll
+            for (int j = 0; j < E::I; ++j) in[j] = init[(size_t)j * pitch + i];
+            E::state_from_init(in, s);
+        }
+        float p[E::P > 0 ? E::P : 1];
+#pragma unroll
+        for (int k = 0; k < E::P; ++k) p[k] = d.params[(size_t)k * ld + i];
+        E::init_hidden(T, c, p, s, h, full_state != 0);
+    }
+    E::observe(s, ob);
+#pragma unroll
+    for (int j = 0; j < E::S; ++j) d.state[j * ld + i] = s[j];
+#pragma unroll
+    for (int j = 0; j < E::H; ++j) d.hidden[j * ld + i] = h[j];
+#pragma unroll
+    for (int j = 0; j < E::O; ++j) d.obs[j * ld + i] = ob[j];
+    d.step[i] = 0;
+    d.ret[i] = 0.f;
+    d.rew[i] = 0.f;
+    d.done[i] = 0;
+    d.failed[i] = 0;
+    d.err[i] = 0;
+    d.yielded[i] = 0;
+}
+
+// re-derive VS_OBS from VS_STATE after a host-side `state` assignment
+template <class E>
+__global__ __launch_bounds__(BLOCK) void k_observe(Dev d) {
+    int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= d.ld) return;
+    float s[E::S], ob[E::O];
+#pragma unroll
+    for (int j = 0; j < E::S; ++j) s[j] = d.state[(size_t)j * d.ld + i];
+    E::observe(s, ob);
+#pragma unroll
+    for (int j = 0; j < E::O; ++j) d.obs[(size_t)j * d.ld + i] = ob[j];
+}
+
+__global__ void k_count_err(const uint8_t* err, int n, unsigned long long* out) {
+    int i = blockIdx.x * BLOCK + threadIdx.x;
+    bool e = i < n && err[i] != 0;
+    unsigned long long m = __ballot(e);
+    if (__lane_id() == 0 && m) atomicAdd(out, (unsigned long long)__popcll(m));
+}
+
+__global__ void k_copy4(const float4* __restrict__ src, float4* __restrict__ dst, size_t n4) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n4; i += stride) dst[i] = src[i];
+}
+
+}  // namespace vs
+
+// ====================================================================================================================
+// host side
+// ====================================================================================================================
+using namespace vs;
+
+struct EnvInfo {
+    const char* name;
+    int S, A, O, P, H, I, K;
+    const char* pnames[MAXP];
+    float nominal[MAXP];
+    float des[MAXS], qd[MAXS], rd[MAXA];
+};
+
+// names/nominal values: get_nominal_domain_param of each env; task defaults: _create_task of each env
+static const EnvInfo ENV_INFO[VS_ENV_COUNT] = {
+    {"omo", Omo::S, Omo::A, Omo::O, Omo::P, Omo::H, Omo::I, Omo::K,
+     {"mass", "stiffness", "damping"},
+     {1.0f, 30.0f, 0.5f},  // one_mass_oscillator.py:82-86
+     {0, 0}, {1e1f, 1e-2f}, {1e-6f}},  // :70-73
+    {"bob", Bob::S, Bob::A, Bob::O, Bob::P, Bob::H, Bob::I, Bob::K,
+     {"gravity_const", "ball_mass", "ball_radius", "beam_mass", "beam_length", "beam_thickness", "friction_coeff",
+      "ang_offset"},
+     {9.81f, 0.5f, 0.1f, 3.0f, 2.0f, 0.1f, 0.05f, 0.0f},  // ball_on_beam.py:77-87
+     {0, 0, 0, 0}, {1e5f, 1e3f, 1e3f, 1e2f}, {1.0f}},  // :100-108
+    {"qq-su", QQ::S, QQ::A, QQ::O, QQ::P, QQ::H, QQ::I, QQ::K,
+     {"gravity_const", "motor_resistance", "motor_back_emf", "mass_rot_pole", "length_rot_pole", "damping_rot_pole",
+      "mass_pend_pole", "length_pend_pole", "damping_pend_pole", "voltage_thold_neg", "voltage_thold_pos"},
+     {9.81f, 8.4f, 0.042f, 0.095f, 0.085f, 5e-6f, 0.024f, 0.129f, 1e-6f, 0.0f, 0.0f},  // quanser_qube.py:54-68
+     {0.0f, PI_F, 0.0f, 0.0f}, {1.0f, 1.0f, 2e-2f, 5e-3f}, {4e-3f}},  // :181-188
+    {"qcp-su", Qcp::S, Qcp::A, Qcp::O, Qcp::P, Qcp::H, Qcp::I, Qcp::K,
+     {"gravity_const", "cart_mass", "rail_length", "motor_efficiency", "gear_efficiency", "gear_ratio",
+      "motor_inertia", "pinion_radius", "motor_resistance", "motor_back_emf", "pole_damping", "combined_damping",
+      "pole_mass", "pole_length", "cart_friction_coeff", "voltage_thold_neg", "voltage_thold_pos"},
+     {9.81f, 0.58f, 0.814f, 0.9f, 0.9f, 3.71f, 3.9e-7f, 6.35e-3f, 2.6f, 7.67e-3f, 0.0024f, 5.4f, 0.127f,
+      0.3365f / 2, 0.02f, 0.0f, 0.0f},  // quanser_cartpole.py:111-143
+     {0.0f, PI_F, 0.0f, 0.0f}, {3e-1f, 5e-1f, 5e-3f, 1e-3f}, {1e-3f}},  // :573-587
+    {"qbb", Qbb::S, Qbb::A, Qbb::O, Qbb::P, Qbb::H, Qbb::I, Qbb::K,
+     {"gravity_const", "ball_mass", "ball_radius", "plate_length", "arm_radius", "gear_ratio", "gear_efficiency",
+      "load_inertia", "motor_inertia", "motor_back_emf", "motor_resistance", "motor_efficiency", "combined_damping",
+      "ball_damping", "voltage_thold_x_pos", "voltage_thold_x_neg", "voltage_thold_y_pos", "voltage_thold_y_neg",
+      "offset_th_x", "offset_th_y"},
+     {9.81f, 0.003f, 0.019625f, 0.275f, 0.0254f, 70.0f, 0.9f, 5.2822e-5f, 4.6063e-7f, 0.0077f, 2.6f, 0.69f, 0.015f,
+      0.05f, 0.28f, -0.10f, 0.28f, -0.074f, 0.0f, 0.0f},  // quanser_ball_balancer.py:141-143,171-202
+     {0, 0, 0, 0, 0, 0, 0, 0}, {1e0f, 1e0f, 5e3f, 5e3f, 1e-2f, 1e-2f, 5e-1f, 5e-1f}, {1e-2f, 1e-2f}}};  // :119-129
+
+struct vs_env {
+    int type = 0;
+    int device = 0;
+    Task task{};
+    DrSpecs dr{};
+    bool auto_reset = false;
+    uint64_t ar_seed = 0;
+    bool uniform = true;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    Dev d{};
+    int traj_cap = 0;
+    uint64_t epoch = 0;
+    std::string err;
+    std::vector<void*> allocs;
+    void* stage = nullptr;
+    size_t stage_bytes = 0;
+    void* stage_mask = nullptr;
+    unsigned long long* d_counter = nullptr;
+};
+
+static thread_local std::string g_create_err;
+
+static int fail(vs_handle h, int code, const char* what, hipError_t e = hipSuccess) {
+    char buf[512];
+    if (e != hipSuccess)
+        snprintf(buf, sizeof buf, "%s: %s (%s)", what, hipGetErrorString(e), hipGetErrorName(e));
+    else
+        snprintf(buf, sizeof buf, "%s", what);
+    if (h) h->err = buf;
+    else g_create_err = buf;
+    return code;
+}
+
+#define HIPCHK(h, x)                                              \
+    do {                                                          \
+        hipError_t e_ = (x);                                      \
+        if (e_ != hipSuccess) return fail(h, VS_ERR_HIP, #x, e_); \
+    } while (0)
+
+#define DISPATCH_ENV(type, ...)                                  \
+    switch (type) {                                              \
+        case VS_ENV_OMO: { using E = Omo; __VA_ARGS__; } break;    \
+        case VS_ENV_BOB: { using E = Bob; __VA_ARGS__; } break;    \
+        case VS_ENV_QQ_SU: { using E = QQ; __VA_ARGS__; } break;   \
+        case VS_ENV_QCP_SU: { using E = Qcp; __VA_ARGS__; } break; \
+        case VS_ENV_QBB: { using E = Qbb; __VA_ARGS__; } break;    \
+        default: break;                                          \
+    }
+
+static inline dim3 grid_for(int ld) { return dim3((unsigned)((ld + BLOCK - 1) / BLOCK)); }
+
+static bool is_device_ptr(const void* p) {
+    hipPointerAttribute_t at;
+    hipError_t e = hipPointerGetAttributes(&at, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();  // clear: plain host memory is reported as an error
+        return false;
+    }
+    return at.type == hipMemoryTypeDevice || at.type == hipMemoryTypeManaged;
+}
+
+template <class T>
+static int dalloc(vs_handle h, T** p, size_t count) {
+    void* q = nullptr;
+    HIPCHK(h, hipMalloc(&q, count * sizeof(T) > 0 ? count * sizeof(T) : 4));
+    HIPCHK(h, hipMemsetAsync(q, 0, count * sizeof(T) > 0 ? count * sizeof(T) : 4, h->stream));
+    h->allocs.push_back(q);
+    *p = (T*)q;
+    return VS_OK;
+}
+
+// stage a host SoA [rows][pitch] into device memory [rows][ld]; device inputs are used in place
+static int stage_rows(vs_handle h, const float* src, int rows, int64_t pitch, const float** out, long* out_pitch) {
+    if (is_device_ptr(src)) {
+        *out = src;
+        *out_pitch = (long)pitch;
+        return VS_OK;
+    }
+    size_t need = (size_t)rows * h->d.ld * sizeof(float);
+    if (need > h->stage_bytes) {
+        if (h->stage) HIPCHK(h, hipFree(h->stage));
+        h->stage = nullptr;
+        h->stage_bytes = 0;
+        HIPCHK(h, hipMalloc(&h->stage, need));
+        h->stage_bytes = need;
+    }
+    HIPCHK(h, hipMemcpy2DAsync(h->stage, (size_t)h->d.ld * 4, src, (size_t)pitch * 4, (size_t)h->d.n * 4, rows,
+                               hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));  // control path: the caller's host buffer may be a temporary
+    *out = (const float*)h->stage;
+    *out_pitch = h->d.ld;
+    return VS_OK;
+}
+
+static int stage_mask(vs_handle h, const uint8_t* mask, const uint8_t** out) {
+    if (!mask) { *out = nullptr; return VS_OK; }
+    if (is_device_ptr(mask)) { *out = mask; return VS_OK; }
+    if (!h->stage_mask) HIPCHK(h, hipMalloc(&h->stage_mask, (size_t)h->d.ld));
+    HIPCHK(h, hipMemcpyAsync(h->stage_mask, mask, (size_t)h->d.n, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    *out = (const uint8_t*)h->stage_mask;
+    return VS_OK;
+}
+
+static int check_specs(vs_handle h, const vs_dp_spec* specs, int n, DrSpecs* out) {
+    const EnvInfo& ei = ENV_INFO[h->type];
+    if (n < 0 || n > MAXP || (n > 0 && !specs)) return fail(h, VS_ERR_ARG, "bad domain-parameter spec list");
+    out->n = n;
+    for (int q = 0; q < n; ++q) {
+        if (specs[q].param_index < 0 || specs[q].param_index >= ei.P) return fail(h, VS_ERR_ARG, "spec param_index out of range");
+        if (specs[q].kind != VS_DP_NORMAL && specs[q].kind != VS_DP_UNIFORM) return fail(h, VS_ERR_ARG, "spec kind must be VS_DP_NORMAL or VS_DP_UNIFORM");
+        if (!(specs[q].spread >= 0.f)) return fail(h, VS_ERR_ARG, "spec spread must be >= 0");
+        out->s[q] = specs[q];
+    }
+    return VS_OK;
+}
+
+template <class E>
+static void launch_step(vs_handle h, const float* act, long es, long ds, uint64_t ep) {
+    dim3 g = grid_for(h->d.ld), b(BLOCK);
+    bool uni = h->uniform && h->dr.n == 0;
+    if (h->auto_reset) {
+        if (uni) hipLaunchKernelGGL((k_step<E, true, true>), g, b, 0, h->stream, h->task, h->d, h->dr, act, es, ds, h->ar_seed, ep);
+        else hipLaunchKernelGGL((k_step<E, false, true>), g, b, 0, h->stream, h->task, h->d, h->dr, act, es, ds, h->ar_seed, ep);
+    } else {
+        if (uni) hipLaunchKernelGGL((k_step<E, true, false>), g, b, 0, h->stream, h->task, h->d, h->dr, act, es, ds, h->ar_seed, ep);
+        else hipLaunchKernelGGL((k_step<E, false, false>), g, b, 0, h->stream, h->task, h->d, h->dr, act, es, ds, h->ar_seed, ep);
+    }
+}
+
+template <class E>
+static void launch_rollout(vs_handle h, int k, uint64_t seed, uint64_t ep, bool rec) {
+    dim3 g = grid_for(h->d.ld), b(BLOCK);
+    bool uni = h->uniform && h->dr.n == 0;
+#define LR(U, AR, R) hipLaunchKernelGGL((k_rollout<E, U, AR, R>), g, b, 0, h->stream, h->task, h->d, h->dr, k, seed, ep)
+    if (uni) {
+        if (h->auto_reset) { if (rec) LR(true, true, true); else LR(true, true, false); }
+        else { if (rec) LR(true, false, true); else LR(true, false, false); }
+    } else {
+        if (h->auto_reset) { if (rec) LR(false, true, true); else LR(false, true, false); }
+        else { if (rec) LR(false, false, true); else LR(false, false, false); }
+    }
+#undef LR
+}
+
+extern "C" {
+
+int vs_version(void) { return 100; }
+
+int vs_env_dims(int t, int* S, int* A, int* O, int* P, int* H, int* I, int* K) {
+    if (t < 0 || t >= VS_ENV_COUNT) return VS_ERR_ARG;
+    const EnvInfo& e = ENV_INFO[t];
+    if (S) *S = e.S;
+    if (A) *A = e.A;
+    if (O) *O = e.O;
+    if (P) *P = e.P;
+    if (H) *H = e.H;
+    if (I) *I = e.I;
+    if (K) *K = e.K;
+    return VS_OK;
+}
+
+const char* vs_env_name(int t) { return (t < 0 || t >= VS_ENV_COUNT) ? nullptr : ENV_INFO[t].name; }
+
+const char* vs_param_name(int t, int i) {
+    if (t < 0 || t >= VS_ENV_COUNT || i < 0 || i >= ENV_INFO[t].P) return nullptr;
+    return ENV_INFO[t].pnames[i];
+}
+
+int vs_nominal_params(int t, int flags, float* out) {
+    if (t < 0 || t >= VS_ENV_COUNT || !out) return VS_ERR_ARG;
+    for (int k = 0; k < ENV_INFO[t].P; ++k) out[k] = ENV_INFO[t].nominal[k];
+    if (t == VS_ENV_QCP_SU && (flags & VS_FLAG_LONG_POLE)) {  // get_nominal_domain_param(long=True), :113-118
+        out[12] = 0.23f;
+        out[13] = 0.641f / 2;
+    }
+    return VS_OK;
+}
+
+const char* vs_last_error(vs_handle h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+int vs_create(int env_type, int64_t n_envs, double dt, int64_t max_steps, int device_id, const vs_task_cfg* cfg,
+              vs_handle* out) {
+    if (!out) return fail(nullptr, VS_ERR_ARG, "vs_create: out is NULL");
+    *out = nullptr;
+    if (env_type < 0 || env_type >= VS_ENV_COUNT) return fail(nullptr, VS_ERR_ARG, "vs_create: unknown env_type");
+    if (n_envs < 1 || n_envs > (1LL << 30)) return fail(nullptr, VS_ERR_ARG, "vs_create: n_envs must be in [1, 2^30]");
+    if (!(dt >= 0.0)) return fail(nullptr, VS_ERR_ARG, "vs_create: dt must be >= 0");  // Env.__init__ base.py:58-59
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0) return fail(nullptr, VS_ERR_HIP, "vs_create: no HIP device available (libvecsim has no CPU fallback)", e);
+    if (device_id < 0 || device_id >= ndev) return fail(nullptr, VS_ERR_ARG, "vs_create: bad device_id");
+    vs_handle h = new (std::nothrow) vs_env();
+    if (!h) return fail(nullptr, VS_ERR_HIP, "vs_create: out of host memory");
+    h->type = env_type;
+    h->device = device_id;
+    const EnvInfo& ei = ENV_INFO[env_type];
+    Task& T = h->task;
+    bool defaults = !cfg || cfg->use_defaults;
+    for (int j = 0; j < MAXS; ++j) {
+        T.des[j] = defaults ? ei.des[j] : cfg->state_des[j];
+        T.qd[j] = defaults ? ei.qd[j] : cfg->q_diag[j];
+    }
+    for (int j = 0; j < MAXA; ++j) T.rd[j] = defaults ? ei.rd[j] : cfg->r_diag[j];
+    T.dt = (float)dt;
+    T.max_steps = (max_steps <= 0 || max_steps >= INT_MAX) ? INT_MAX : (int)max_steps;
+    T.flags = cfg ? cfg->flags : 0;
+    T.wild_init = cfg ? cfg->wild_init : 0;
+    int rc = VS_OK;
+#define CK(x) do { rc = (x); if (rc != VS_OK) { g_create_err = h->err; vs_destroy(h); return rc; } } while (0)
+#define HK(x) do { hipError_t e2 = (x); if (e2 != hipSuccess) { fail(nullptr, VS_ERR_HIP, #x, e2); vs_destroy(h); return VS_ERR_HIP; } } while (0)
+    HK(hipSetDevice(device_id));
+    HK(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+    h->stream = h->own_stream;
+    Dev& d = h->d;
+    d.n = (int)n_envs;
+    d.ld = (int)(((n_envs + BLOCK - 1) / BLOCK) * BLOCK);
+    size_t ld = d.ld;
+    CK(dalloc(h, &d.state, ei.S * ld));
+    CK(dalloc(h, &d.hidden, (ei.H > 0 ? ei.H : 1) * ld));
+    CK(dalloc(h, &d.obs, ei.O * ld));
+    CK(dalloc(h, &d.rew, ld));
+    CK(dalloc(h, &d.ret, ld));
+    CK(dalloc(h, &d.consts, ei.K * ld));
+    CK(dalloc(h, &d.params, ei.P * ld));
+    CK(dalloc(h, &d.consts_uni, (size_t)MAXK));
+    CK(dalloc(h, &d.done, ld));
+    CK(dalloc(h, &d.failed, ld));
+    CK(dalloc(h, &d.err, ld));
+    CK(dalloc(h, &d.yielded, ld));
+    CK(dalloc(h, &d.step, ld));
+    d.ep_cap = (unsigned)(ld < (1u << 16) ? (1u << 16) : ld);
+    CK(dalloc(h, &d.ep_ret, (size_t)d.ep_cap));
+    CK(dalloc(h, &d.ep_len, (size_t)d.ep_cap));
+    CK(dalloc(h, &d.ep_env, (size_t)d.ep_cap));
+    CK(dalloc(h, &d.ep_count, (size_t)1));
+    CK(dalloc(h, &h->d_counter, (size_t)1));
+    float nominal[MAXP];
+    vs_nominal_params(env_type, T.flags, nominal);
+    CK(vs_set_params_uniform(h, nominal));
+    CK(vs_reset(h, nullptr, 0, 0, nullptr, 0));
+    HK(hipStreamSynchronize(h->stream));
+#undef CK
+#undef HK
+    *out = h;
+    return VS_OK;
+}
+
+int vs_destroy(vs_handle h) {
+    if (!h) return VS_OK;
+    (void)hipSetDevice(h->device);
+    if (h->own_stream) (void)hipStreamSynchronize(h->own_stream);
+    for (void* p : h->allocs) (void)hipFree(p);
+    if (h->stage) (void)hipFree(h->stage);
+    if (h->stage_mask) (void)hipFree(h->stage_mask);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    delete h;
+    return VS_OK;
+}
+
+int vs_set_stream(vs_handle h, void* s) {
+    if (!h) return VS_ERR_ARG;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    h->stream = s ? (hipStream_t)s : h->own_stream;
+    return VS_OK;
+}
+
+int vs_sync(vs_handle h) {
+    if (!h) return VS_ERR_ARG;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return VS_OK;
+}
+
+int64_t vs_n_envs(vs_handle h) { return h ? h->d.n : -1; }
+int64_t vs_ld(vs_handle h) { return h ? h->d.ld : -1; }
+
+int vs_set_params(vs_handle h, const float* params_soa, int64_t pitch, const uint8_t* mask) {
+    if (!h || !params_soa) return fail(h, VS_ERR_ARG, "vs_set_params: NULL argument");
+    if (pitch < h->d.n) return fail(h, VS_ERR_ARG, "vs_set_params: pitch < n_envs");
+    HIPCHK(h, hipSetDevice(h->device));
+    const float* src; long sp; const uint8_t* m;
+    int rc = stage_rows(h, params_soa, ENV_INFO[h->type].P, pitch, &src, &sp);
+    if (rc) return rc;
+    rc = stage_mask(h, mask, &m);
+    if (rc) return rc;
+    h->uniform = false;
+    DISPATCH_ENV(h->type, hipLaunchKernelGGL(k_set_params<E>, grid_for(h->d.ld), dim3(BLOCK), 0, h->stream, h->task,
+                                              h->d, src, sp, 0, m));
+    HIPCHK(h, hipGetLastError());
+    return VS_OK;
+}
+
+int vs_set_params_uniform(vs_handle h, const float* params) {
+    if (!h || !params) return fail(h, VS_ERR_ARG, "vs_set_params_uniform: NULL argument");
+    HIPCHK(h, hipSetDevice(h->device));
+    int P = ENV_INFO[h->type].P;
+    if (h->stage_bytes < (size_t)MAXP * 4) {
+        if (h->stage) HIPCHK(h, hipFree(h->stage));
+        h->stage_bytes = 0;
+        HIPCHK(h, hipMalloc(&h->stage, (size_t)MAXP * 4));
+        h->stage_bytes = (size_t)MAXP * 4;
+    }
+    HIPCHK(h, hipMemcpyAsync(h->stage, params, (size_t)P * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));  // `params` may be a temporary of the caller
+    h->uniform = true;
+    DISPATCH_ENV(h->type, hipLaunchKernelGGL(k_set_params<E>, grid_for(h->d.ld), dim3(BLOCK), 0, h->stream, h->task,
+                                              h->d, (const float*)h->stage, 0L, 1, (const uint8_t*)nullptr));
+    HIPCHK(h, hipGetLastError());
+    return VS_OK;
+}
+
+int vs_sample_params(vs_handle h, const vs_dp_spec* specs, int n_specs, uint64_t seed, const uint8_t* mask) {
+    if (!h) return VS_ERR_ARG;
+    DrSpecs dr;
+    int rc = check_specs(h, specs, n_specs, &dr);
+    if (rc) return rc;
+    if (n_specs == 0) return VS_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    const uint8_t* m;
+    rc = stage_mask(h, mask, &m);
+    if (rc) return rc;
+    h->uniform = false;
+    uint64_t ep = h->epoch++;
+    DISPATCH_ENV(h->type, hipLaunchKernelGGL(k_sample_params<E>, grid_for(h->d.ld), dim3(BLOCK), 0, h->stream,
+                                              h->task, h->d, dr, seed, ep, m));
+    HIPCHK(h, hipGetLastError());
+    return VS_OK;
+}
+
+int vs_set_randomizer(vs_handle h, const vs_dp_spec* specs, int n_specs) {
+    if (!h) return VS_ERR_ARG;
+    DrSpecs dr;
+    int rc = check_specs(h, specs, n_specs, &dr);
+    if (rc) return rc;
+    h->dr = dr;
+    if (n_specs > 0) h->uniform = false;
+    return VS_OK;
+}
+
+int vs_reset(vs_handle h, const float* init_state, int64_t pitch, int full, const uint8_t* mask, uint64_t seed) {
+    if (!h) return VS_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    const EnvInfo& ei = ENV_INFO[h->type];
+    const float* src = nullptr; long sp = 0; const uint8_t* m;
+    int rc;
+    if (init_state) {
+        if (pitch < h->d.n) return fail(h, VS_ERR_ARG, "vs_reset: pitch < n_envs");
+        rc = stage_rows(h, init_state, full ? ei.S : ei.I, pitch, &src, &sp);
+        if (rc) return rc;
+    }
+    rc = stage_mask(h, mask, &m);
+    if (rc) return rc;
+    uint64_t ep = h->epoch++;
+    DISPATCH_ENV(h->type, hipLaunchKernelGGL(k_reset<E>, grid_for(h->d.ld), dim3(BLOCK), 0, h->stream, h->task, h->d,
+                                              h->dr, src, sp, full, m, seed, ep));
+    HIPCHK(h, hipGetLastError());
+    return VS_OK;
+}
+
+int vs_set_auto_reset(vs_handle h, int on, uint64_t seed) {
+    if (!h) return VS_ERR_ARG;
+    h->auto_reset = on != 0;
+    h->ar_seed = seed;
+    return VS_OK;
+}
+
+int vs_step(vs_handle h, const float* actions, int64_t env_stride, int64_t dim_stride) {
+    if (!h || !actions) return fail(h, VS_ERR_ARG, "vs_step: NULL argument");
+    if (!is_device_ptr(actions)) return fail(h, VS_ERR_ARG, "vs_step: actions must be device memory");
+    HIPCHK(h, hipSetDevice(h->device));
+    uint64_t ep = h->epoch++;
+    DISPATCH_ENV(h->type, launch_step<E>(h, actions, (long)env_stride, (long)dim_stride, ep));
+    HIPCHK(h, hipGetLastError());
+    return VS_OK;
+}
+
+int vs_set_traj_capacity(vs_handle h, int t_max) {
+    if (!h || t_max < 0) return fail(h, VS_ERR_ARG, "vs_set_traj_capacity: bad argument");
+    if (t_max <= h->traj_cap) return VS_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    const EnvInfo& ei = ENV_INFO[h->type];
+    Dev& d = h->d;
+    size_t ld = d.ld;
+    // old buffers stay in h->allocs until destroy (capacity only grows a handful of times)
+    int rc;
+    if ((rc = dalloc(h, &d.traj_obs, (size_t)t_max * ei.O * ld))) return rc;
+    if ((rc = dalloc(h, &d.traj_act, (size_t)t_max * ei.A * ld))) return rc;
+    if ((rc = dalloc(h, &d.traj_rew, (size_t)t_max * ld))) return rc;
+    if ((rc = dalloc(h, &d.traj_done, (size_t)t_max * ld))) return rc;
+    h->traj_cap = t_max;
+    return VS_OK;
+}
+
+int vs_step_random(vs_handle h, uint64_t seed, int k_steps, int record) {
+    if (!h || k_steps < 1) return fail(h, VS_ERR_ARG, "vs_step_random: bad argument");
+    if (record && k_steps > h->traj_cap) return fail(h, VS_ERR_STATE, "vs_step_random: k_steps exceeds vs_set_traj_capacity");
+    HIPCHK(h, hipSetDevice(h->device));
+    uint64_t ep = h->epoch;
+    h->epoch += (uint64_t)k_steps;
+    DISPATCH_ENV(h->type, launch_rollout<E>(h, k_steps, seed, ep, record != 0));
+    HIPCHK(h, hipGetLastError());
+    return VS_OK;
+}
+
+int vs_clear_episodes(vs_handle h) {
+    if (!h) return VS_ERR_ARG;
+    HIPCHK(h, hipMemsetAsync(h->d.ep_count, 0, sizeof(unsigned), h->stream));
+    return VS_OK;
+}
+
+static bool buf_info(vs_handle h, int which, void** p, size_t* bytes) {
+    const EnvInfo& ei = ENV_INFO[h->type];
+    Dev& d = h->d;
+    size_t ld = d.ld;
+    switch (which) {
+        case VS_STATE: *p = d.state; *bytes = ei.S * ld * 4; return true;
+        case VS_OBS: *p = d.obs; *bytes = ei.O * ld * 4; return true;
+        case VS_REW: *p = d.rew; *bytes = ld * 4; return true;
+        case VS_DONE: *p = d.done; *bytes = ld; return true;
+        case VS_HIDDEN: *p = d.hidden; *bytes = (size_t)ei.H * ld * 4; return true;
+        case VS_STEPCOUNT: *p = d.step; *bytes = ld * 4; return true;
+        case VS_ERRFLAG: *p = d.err; *bytes = ld; return true;
+        case VS_RETURNS: *p = d.ret; *bytes = ld * 4; return true;
+        case VS_PARAMS: *p = d.params; *bytes = ei.P * ld * 4; return true;
+        case VS_CONSTS: *p = d.consts; *bytes = ei.K * ld * 4; return true;
+        case VS_EP_RETURNS: *p = d.ep_ret; *bytes = (size_t)d.ep_cap * 4; return true;
+        case VS_EP_LENGTHS: *p = d.ep_len; *bytes = (size_t)d.ep_cap * 4; return true;
+        case VS_EP_ENVIDX: *p = d.ep_env; *bytes = (size_t)d.ep_cap * 4; return true;
+        case VS_EP_COUNT: *p = d.ep_count; *bytes = 4; return true;
+        case VS_TRAJ_OBS: *p = d.traj_obs; *bytes = (size_t)h->traj_cap * ei.O * ld * 4; return true;
+        case VS_TRAJ_ACT: *p = d.traj_act; *bytes = (size_t)h->traj_cap * ei.A * ld * 4; return true;
+        case VS_TRAJ_REW: *p = d.traj_rew; *bytes = (size_t)h->traj_cap * ld * 4; return true;
+        case VS_TRAJ_DONE: *p = d.traj_done; *bytes = (size_t)h->traj_cap * ld; return true;
+        case VS_FAILED: *p = d.failed; *bytes = ld; return true;
+        default: return false;
+    }
+}
+
+void* vs_get(vs_handle h, int which) {
+    if (!h) return nullptr;
+    void* p; size_t b;
+    if (!buf_info(h, which, &p, &b)) { fail(h, VS_ERR_ARG, "vs_get: unknown buffer"); return nullptr; }
+    return p;
+}
+
+int vs_copy_to_host(vs_handle h, int which, void* dst) {
+    if (!h || !dst) return fail(h, VS_ERR_ARG, "vs_copy_to_host: NULL argument");
+    void* p; size_t b;
+    if (!buf_info(h, which, &p, &b)) return fail(h, VS_ERR_ARG, "vs_copy_to_host: unknown buffer");
+    if (b == 0) return VS_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpyAsync(dst, p, b, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return VS_OK;
+}
+
+int vs_copy_from_host(vs_handle h, int which, const void* src) {
+    if (!h || !src) return fail(h, VS_ERR_ARG, "vs_copy_from_host: NULL argument");
+    if (which != VS_STATE && which != VS_HIDDEN && which != VS_STEPCOUNT)
+        return fail(h, VS_ERR_ARG, "vs_copy_from_host: only VS_STATE / VS_HIDDEN / VS_STEPCOUNT are assignable");
+    void* p; size_t b;
+    buf_info(h, which, &p, &b);
+    if (b == 0) return VS_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpyAsync(p, src, b, hipMemcpyHostToDevice, h->stream));
+    if (which == VS_STATE) {
+        DISPATCH_ENV(h->type, hipLaunchKernelGGL(k_observe<E>, grid_for(h->d.ld), dim3(BLOCK), 0, h->stream, h->d));
+        HIPCHK(h, hipGetLastError());
+    }
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return VS_OK;
+}
+
+int64_t vs_error_count(vs_handle h) {
+    if (!h) return -1;
+    if (hipSetDevice(h->device) != hipSuccess) return -1;
+    if (hipMemsetAsync(h->d_counter, 0, 8, h->stream) != hipSuccess) return -1;
+    hipLaunchKernelGGL(k_count_err, grid_for(h->d.ld), dim3(BLOCK), 0, h->stream, h->d.err, h->d.n, h->d_counter);
+    unsigned long long v = 0;
+    if (hipMemcpyAsync(&v, h->d_counter, 8, hipMemcpyDeviceToHost, h->stream) != hipSuccess) return -1;
+    if (hipStreamSynchronize(h->stream) != hipSuccess) return -1;
+    return (int64_t)v;
+}
+
+int vs_time_step_kernel(vs_handle h, int mode, const float* actions, int64_t env_stride, int64_t dim_stride,
+                        int k_steps, int record, int iters, float* avg_ms) {
+    if (!h || !avg_ms || iters < 1) return fail(h, VS_ERR_ARG, "vs_time_step_kernel: bad argument");
+    HIPCHK(h, hipSetDevice(h->device));
+    hipEvent_t e0, e1;
+    HIPCHK(h, hipEventCreate(&e0));
+    HIPCHK(h, hipEventCreate(&e1));
+    int rc = VS_OK;
+    // events on the stream the kernels are launched on; one warm launch first
+    rc = mode == 0 ? vs_step(h, actions, env_stride, dim_stride) : vs_step_random(h, 1234, k_steps, record);
+    if (rc == VS_OK) {
+        (void)hipEventRecord(e0, h->stream);
+        for (int it = 0; it < iters && rc == VS_OK; ++it)
+            rc = mode == 0 ? vs_step(h, actions, env_stride, dim_stride) : vs_step_random(h, 1234, k_steps, record);
+        (void)hipEventRecord(e1, h->stream);
+        hipError_t e = hipEventSynchronize(e1);
+        float ms = 0.f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        if (e != hipSuccess) rc = fail(h, VS_ERR_HIP, "vs_time_step_kernel: event timing", e);
+        *avg_ms = ms / (float)iters;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return rc;
+}
+
+int vs_membw_probe(int device_id, int64_t bytes, int iters, float* gbps) {
+    if (!gbps || bytes < (1 << 20) || iters < 1) return VS_ERR_ARG;
+    if (hipSetDevice(device_id) != hipSuccess) return VS_ERR_HIP;
+    void *a = nullptr, *b = nullptr;
+    size_t n4 = (size_t)bytes / 16;
+    if (hipMalloc(&a, n4 * 16) != hipSuccess) return VS_ERR_HIP;
+    if (hipMalloc(&b, n4 * 16) != hipSuccess) { (void)hipFree(a); return VS_ERR_HIP; }
+    (void)hipMemset(a, 1, n4 * 16);
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    hipLaunchKernelGGL(k_copy4, dim3(2048), dim3(256), 0, 0, (const float4*)a, (float4*)b, n4);
+    (void)hipEventRecord(e0, 0);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(k_copy4, dim3(2048), dim3(256), 0, 0, (const float4*)a, (float4*)b, n4);
+    (void)hipEventRecord(e1, 0);
+    hipError_t e = hipEventSynchronize(e1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(a);
+    (void)hipFree(b);
+    if (e != hipSuccess || ms <= 0.f) return VS_ERR_HIP;
+    *gbps = (float)(2.0 * (double)(n4 * 16) * iters / (ms * 1e-3) / 1e9);  // read + write
+    return VS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,512 @@
+// vecsim_envs.h -- per-environment device code (fp32, one environment per wavefront lane) for libvecsim.
+//
+// Each struct restates one Pyrado SimPyEnv family for CDNA4; reference file:line is given at every function.
+// `P/` = Pyrado/pyrado/ of swami1995/SimuRLacra.  Quirk numbers (Q1..Q15) refer to SURVEY.md section 0.
+//
+// Layout contract shared with vecsim.hip and the Python shim:
+//   params[P]  raw domain parameters in get_nominal_domain_param() order
+//   consts[K]  derived constants; the first KS of them are what one step() reads, the rest are reset-only
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vs {
+
+constexpr int MAXS = 8, MAXA = 2, MAXO = 8, MAXH = 2, MAXP = 20, MAXK = 20;
+constexpr double PI_D = 3.14159265358979323846;
+constexpr float PI_F = (float)PI_D;
+// bounds are the fp64 expressions of the reference rounded once to fp32 (not re-derived in fp32 arithmetic)
+constexpr float PI_4_F = (float)(PI_D / 4.0), PI4_F = (float)(4.0 * PI_D), PI5_F = (float)(5.0 * PI_D),
+                PI20_F = (float)(20.0 * PI_D), QQ_TH_MAX_F = (float)(115.0 / 180.0 * PI_D);
+constexpr float TWO_PI_F = 6.28318530717958647692f;
+// 2*pi = TWO_PI_HI + TWO_PI_LO with TWO_PI_HI == (float)2pi: two-term reduction keeps fmod(err, 2pi) at fp64 quality
+constexpr float TWO_PI_HI = 6.28318548202514648437500f;
+constexpr float TWO_PI_LO = -1.74845553146951715461910e-07f;
+
+enum RewKind { REW_QUADR = 0, REW_EXP = 1, REW_SCALED_EXP = 2 };
+
+// Task + ctor configuration: a by-value kernel argument (wave-uniform, lands in SGPRs / scalar loads)
+struct Task {
+    float des[MAXS];  // DesStateTask.state_des            P/tasks/desired_state.py:57
+    float qd[MAXS];   // diag(Q)                            P/tasks/reward_functions.py:202-221
+    float rd[MAXA];   // diag(R)
+    float dt;
+    int max_steps;  // INT_MAX == pyrado.inf
+    int flags;      // VS_FLAG_*
+    int wild_init;  // qcp only
+};
+
+// ------------------------------------------------------------------------------------------------- small helpers
+__device__ __forceinline__ float sqr(float x) { return x * x; }
+
+// np.fmod(e, 2*pi) for |e| < ~2^20 (P/tasks/desired_state.py:149): truncated quotient, exact remainder via FMA,
+// 2pi split in hi+lo so the fp32 result tracks the fp64 one to ~1 ulp of e
+__device__ __forceinline__ float fmod_2pi(float e) {
+    float q = truncf(e * (1.0f / TWO_PI_F));
+    float r = fmaf(-q, TWO_PI_HI, e);
+    r = fmaf(-q, TWO_PI_LO, r);
+    // q may be off by one when e/2pi rounds across an integer: bring r back to (-2pi, 2pi) with the sign of e
+    if (e >= 0.f) {
+        if (r < 0.f) r += TWO_PI_F;
+        if (r >= TWO_PI_F) r -= TWO_PI_F;
+    } else {
+        if (r > 0.f) r -= TWO_PI_F;
+        if (r <= -TWO_PI_F) r += TWO_PI_F;
+    }
+    return r;
+}
+
+// the two sequential +-pi folds of RadiallySymmDesStateTask.step_rew (P/tasks/desired_state.py:152-153, Q4)
+__device__ __forceinline__ float fold_pi(float e) {
+    if (e > PI_F) e = TWO_PI_F - e;
+    if (e < -PI_F) e = -TWO_PI_F - e;
+    return e;
+}
+
+__device__ __forceinline__ float sgnf(float x) { return (float)(x > 0.f) - (float)(x < 0.f); }  // np.sign
+
+// ------------------------------------------------------------------------------------------------- Philox4x32-10
+struct Rng {
+    uint2 key;
+    uint4 ctr;
+    uint4 out;
+    int used;
+    __device__ __forceinline__ Rng(uint64_t seed, uint32_t env, uint32_t purpose, uint64_t t) {
+        key = make_uint2((uint32_t)seed, (uint32_t)(seed >> 32));
+        ctr = make_uint4(env, purpose, (uint32_t)t, (uint32_t)(t >> 32));
+        used = 4;
+    }
+    __device__ __forceinline__ void block() {
+        uint4 c = ctr;
+        uint2 k = key;
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+            uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+            c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
+            k.x += 0x9E3779B9u;
+            k.y += 0xBB67AE85u;
+        }
+        out = c;
+        ctr.y += 0x10000u;  // next block of the same (env, purpose, t) stream; purposes stay below 2^16
+        used = 0;
+    }
+    __device__ __forceinline__ uint32_t next() {
+        if (used == 4) block();
+        uint32_t v = used == 0 ? out.x : used == 1 ? out.y : used == 2 ? out.z : out.w;
+        ++used;
+        return v;
+    }
+    __device__ __forceinline__ float u01() { return (float)(next() >> 8) * (1.0f / 16777216.0f); }  // [0, 1)
+    __device__ __forceinline__ float uniform(float lo, float hi) { return lo + (hi - lo) * u01(); }
+    __device__ __forceinline__ float normal() {  // Box-Muller, one value per two uniforms
+        float u1 = 1.0f - u01();                 // (0, 1]
+        float u2 = u01();
+        return sqrtf(-2.0f * logf(u1)) * cosf(TWO_PI_F * u2);
+    }
+};
+enum RngPurpose { RNG_ACT = 1, RNG_INIT = 2, RNG_PARAM = 3 };
+
+// =================================================================================================== OMO
+// OneMassOscillatorSim, P/environments/pysim/one_mass_oscillator.py:49-121
+struct Omo {
+    static constexpr int S = 2, A = 1, O = 2, H = 0, I = 2, P = 3, K = 4, KS = 4;
+    static constexpr int REW = REW_QUADR, RADIAL = -1, CMAX = -1;
+    static constexpr bool HAS_FINAL = true;  // FinalRewTask(factor 1e3, always_negative), :75-79
+    enum { C_A10, C_A11, C_B1, C_AMAX };
+    __device__ static void calc_consts(const Task&, const float* p, float* c) {  // _calc_constants :88-103
+        float m = p[0], k = p[1], d = p[2];
+        float omega = sqrtf(k / m);
+        float zeta = d / (2.0f * sqrtf(m * k));
+        c[C_A10] = -(omega * omega);        // A[1,0], _step_dynamics :109
+        c[C_A11] = -2.0f * zeta * omega;    // A[1,1]
+        c[C_B1] = 1.0f / m;                 // B[1]
+        c[C_AMAX] = 1.0f * k;               // max_act = max_state[0] * k, _create_spaces :61
+    }
+    __device__ static void state_bounds(const float*, float* lo, float* hi) {  // :58,64
+        hi[0] = 1.0f; hi[1] = 10.0f; lo[0] = -1.0f; lo[1] = -10.0f;
+    }
+    __device__ static void act_bounds(const float* c, float* lo, float* hi) { hi[0] = c[C_AMAX]; lo[0] = -c[C_AMAX]; }
+    __device__ static void dynamics(const Task& T, const float* c, float* s, float*, const float* a) {  // :105-114
+        float sd0 = s[1];
+        float sd1 = c[C_A10] * s[0] + c[C_A11] * s[1] + c[C_B1] * a[0];
+        s[0] = s[0] + sd0 * T.dt;  // forward Euler
+        s[1] = s[1] + sd1 * T.dt;
+    }
+    __device__ static void observe(const float* s, float* o) { o[0] = s[0]; o[1] = s[1]; }
+    __device__ static void sample_init(const Task&, const float*, Rng& g, float* init) {  // :59-60, box.py:169-178
+        init[0] = g.uniform(-0.75f, -0.65f);
+        init[1] = g.uniform(-0.1f, 0.1f);
+    }
+    __device__ static void state_from_init(const float* init, float* s) { s[0] = init[0]; s[1] = init[1]; }
+    __device__ static void init_hidden(const Task&, const float*, const float*, const float*, float*, bool) {}
+};
+
+// =================================================================================================== BoB
+// BallOnBeamSim, P/environments/pysim/ball_on_beam.py:41-136
+struct Bob {
+    static constexpr int S = 4, A = 1, O = 4, H = 0, I = 4, P = 8, K = 9, KS = 9;
+    static constexpr int REW = REW_SCALED_EXP, RADIAL = -1;
+    static constexpr bool HAS_FINAL = false;
+    enum { C_MG, C_M, C_FRICT, C_OFF, C_ZETA_BALL, C_J_BEAM, C_XMAX, C_AMAX, C_CMAX };
+    static constexpr int CMAX = C_CMAX;
+    __device__ static void calc_consts(const Task& T, const float* p, float* c) {  // _calc_constants :89-98
+        float g = p[0], m_ball = p[1], r_ball = p[2], m_beam = p[3], l_beam = p[4], d_beam = p[5];
+        float J_ball = 2.0f / 5 * m_ball * r_ball * r_ball;
+        c[C_J_BEAM] = 1.0f / 12 * m_beam * (l_beam * l_beam + d_beam * d_beam);
+        c[C_ZETA_BALL] = m_ball + J_ball / (r_ball * r_ball);
+        c[C_MG] = m_ball * g;
+        c[C_M] = m_ball;
+        c[C_FRICT] = p[6];
+        c[C_OFF] = p[7];
+        c[C_XMAX] = l_beam / 2.0f;               // _create_spaces :54
+        c[C_AMAX] = l_beam / 2.0f * g * 3.0f;    // :55
+        // ScaledExpQuadrErrRewFcn.reset (reward_functions.py:284-297), recomputed per env (Q11)
+        float smax[4] = {c[C_XMAX], PI_4_F, 10.0f, PI_F};
+        float mc = 0.f;
+        for (int j = 0; j < 4; ++j) mc += smax[j] * (T.qd[j] * smax[j]);
+        mc += c[C_AMAX] * (T.rd[0] * c[C_AMAX]);
+        c[C_CMAX] = 9.210340371976182f / mc;  // -ln(1e-4)
+    }
+    __device__ static void state_bounds(const float* c, float* lo, float* hi) {
+        hi[0] = c[C_XMAX]; hi[1] = PI_4_F; hi[2] = 10.0f; hi[3] = PI_F;
+        for (int j = 0; j < 4; ++j) lo[j] = -hi[j];
+    }
+    __device__ static void act_bounds(const float* c, float* lo, float* hi) { hi[0] = c[C_AMAX]; lo[0] = -c[C_AMAX]; }
+    __device__ static void dynamics(const Task& T, const float* c, float* s, float*, const float* act) {  // :110-129
+        float x = s[0], a = s[1] + c[C_OFF], x_dot = s[2], a_dot = s[3];
+        float sa, ca;
+        sincosf(a, &sa, &ca);
+        float zeta_beam = c[C_M] * x * x + c[C_J_BEAM];
+        float x_ddot = (-c[C_FRICT] * x_dot + c[C_M] * x * a_dot * a_dot - c[C_MG] * sa) / c[C_ZETA_BALL];
+        float a_ddot = (act[0] - 2.0f * c[C_M] * x * x_dot * a_dot - c[C_MG] * ca * x) / zeta_beam;
+        s[2] += x_ddot * T.dt;  // symplectic Euler: velocity first
+        s[3] += a_ddot * T.dt;
+        s[0] += s[2] * T.dt;
+        s[1] += s[3] * T.dt;
+    }
+    __device__ static void observe(const float* s, float* o) {
+        for (int j = 0; j < 4; ++j) o[j] = s[j];
+    }
+    __device__ static void sample_init(const Task&, const float* c, Rng& g, float* init) {  // :60-73, compound.py:84-87
+        bool right = (g.next() & 1u) != 0u;  // np.random.randint(2)
+        float l2 = c[C_XMAX];
+        float x = g.uniform(0.7f * l2, 0.8f * l2);
+        init[0] = right ? x : -x;  // box 0: [-0.8, -0.7] l/2, box 1: [0.7, 0.8] l/2
+        init[1] = g.uniform(-5.0f / 180.0f * PI_F, 5.0f / 180.0f * PI_F);
+        init[2] = g.uniform(-0.2f, 0.2f);
+        init[3] = g.uniform(-0.02f * PI_F, 0.02f * PI_F);
+    }
+    __device__ static void state_from_init(const float* init, float* s) {
+        for (int j = 0; j < 4; ++j) s[j] = init[j];
+    }
+    __device__ static void init_hidden(const Task&, const float*, const float*, const float*, float*, bool) {}
+};
+
+// =================================================================================================== QQube
+// QQubeSwingUpSim, P/environments/pysim/quanser_qube.py:41-188
+struct QQ {
+    static constexpr int S = 4, A = 1, O = 6, H = 0, I = 4, P = 11, K = 11, KS = 11;
+    static constexpr int REW = REW_EXP, RADIAL = 1, CMAX = -1;
+    static constexpr bool HAS_FINAL = false;
+    enum { C_C0, C_C1, C_C2, C_C3, C_C4, C_KM, C_RM, C_DR, C_DP, C_TH_NEG, C_TH_POS };
+    __device__ static void calc_consts(const Task&, const float* p, float* c) {  // _calc_constants :70-87
+        float g = p[0], Rm = p[1], km = p[2], mr = p[3], Lr = p[4], Dr = p[5], mp = p[6], Lp = p[7], Dp = p[8];
+        float Jr = mr * Lr * Lr / 12.0f;
+        float Jp = mp * Lp * Lp / 12.0f;
+        c[C_C0] = Jr + mp * Lr * Lr;
+        c[C_C1] = 0.25f * mp * Lp * Lp;
+        c[C_C2] = 0.5f * mp * Lp * Lr;
+        c[C_C3] = Jp + c[C_C1];
+        c[C_C4] = 0.5f * mp * Lp * g;
+        c[C_KM] = km; c[C_RM] = Rm; c[C_DR] = Dr; c[C_DP] = Dp;
+        c[C_TH_NEG] = p[9]; c[C_TH_POS] = p[10];
+    }
+    __device__ static void state_bounds(const float*, float* lo, float* hi) {  // _create_spaces :169
+        hi[0] = QQ_TH_MAX_F; hi[1] = PI4_F; hi[2] = PI20_F; hi[3] = PI20_F;
+        for (int j = 0; j < 4; ++j) lo[j] = -hi[j];
+    }
+    __device__ static void act_bounds(const float*, float* lo, float* hi) { hi[0] = 4.5f; lo[0] = -4.5f; }  // MAX_ACT_QQ
+    __device__ static void dynamics(const Task& T, const float* c, float* s, float*, const float* act) {
+        // dead zone, _step_dynamics :130-131
+        float u = act[0];
+        if (c[C_TH_NEG] <= u && u <= c[C_TH_POS]) u = 0.f;
+        // _dyn :89-125, evaluated once: the reference's "RK4" re-evaluates _dyn at self.state in every stage (Q1), so
+        // k_j differ only in their position-derivative slots and the update collapses to
+        //   v' = v + dt a,  p' = p + dt v + dt^2/2 a        (closed form verified against the oracle: max abs diff 0)
+        float thd = s[2], ald = s[3];
+        float sin_al, cos_al;
+        sincosf(s[1], &sin_al, &cos_al);
+        float sin_2al = 2.0f * sin_al * cos_al;
+        float a = c[C_C0] + c[C_C1] * sin_al * sin_al;
+        float b = c[C_C2] * cos_al;
+        float cc = c[C_C3];
+        float det = a * cc - b * b;
+        float trq = c[C_KM] * (u - c[C_KM] * thd) / c[C_RM];
+        float c0 = c[C_C1] * sin_2al * thd * ald - c[C_C2] * sin_al * ald * ald;
+        float c1 = -0.5f * c[C_C1] * sin_2al * thd * thd + c[C_C4] * sin_al;
+        float x = trq - c[C_DR] * thd - c0;
+        float y = -c[C_DP] * ald - c1;
+        float inv_det = 1.0f / det;
+        float thdd = (cc * x - b * y) * inv_det;
+        float aldd = (a * y - b * x) * inv_det;
+        float dt = T.dt, hdt2 = 0.5f * dt * dt;
+        s[0] = s[0] + dt * thd + hdt2 * thdd;
+        s[1] = s[1] + dt * ald + hdt2 * aldd;
+        s[2] = thd + dt * thdd;
+        s[3] = ald + dt * aldd;
+    }
+    __device__ static void observe(const float* s, float* o) {  // :148-149
+        sincosf(s[0], &o[0], &o[1]);
+        sincosf(s[1], &o[2], &o[3]);
+        o[4] = s[2];
+        o[5] = s[3];
+    }
+    __device__ static void sample_init(const Task&, const float*, Rng& g, float* init) {  // :170
+        const float d2r = PI_F / 180.0f;
+        init[0] = g.uniform(-2.0f * d2r, 2.0f * d2r);
+        init[1] = g.uniform(-1.0f * d2r, 1.0f * d2r);
+        init[2] = g.uniform(-0.5f * d2r, 0.5f * d2r);
+        init[3] = g.uniform(-0.5f * d2r, 0.5f * d2r);
+    }
+    __device__ static void state_from_init(const float* init, float* s) {
+        for (int j = 0; j < 4; ++j) s[j] = init[j];
+    }
+    __device__ static void init_hidden(const Task&, const float*, const float*, const float*, float*, bool) {}
+};
+
+// =================================================================================================== QCartPole
+// QCartPoleSwingUpSim, P/environments/pysim/quanser_cartpole.py:45-230, 507-587; rk4 591-655
+struct Qcp {
+    static constexpr int S = 4, A = 1, O = 5, H = 1, I = 4, P = 17, K = 16, KS = 16;
+    static constexpr int REW = REW_EXP, RADIAL = 1, CMAX = -1;
+    static constexpr bool HAS_FINAL = false;
+    enum { C_KA, C_ETA_M, C_KB, C_MTG, C_MPL2, C_MU, C_M00, C_MPL, C_M11, C_BEQ, C_BP, C_MPLG, C_TH_NEG, C_TH_POS,
+           C_XMAX, C_XDMAX };
+    __device__ static void calc_consts(const Task&, const float* p, float* c) {  // _calc_constants :145-155 + _dynamics
+        float g = p[0], m_c = p[1], l_rail = p[2], eta_m = p[3], eta_g = p[4], K_g = p[5], J_m = p[6], r_mp = p[7],
+              R_m = p[8], k_m = p[9], B_p = p[10], B_eq = p[11], m_p = p[12], l_p = p[13], mu_c = p[14];
+        float J_pole = l_p * l_p * m_p / 3.0f;
+        float J_eq = m_c + (eta_g * K_g * K_g * J_m) / (r_mp * r_mp);
+        c[C_KA] = (eta_g * K_g * eta_m * k_m) / (R_m * r_mp);  // f_act prefactor :195
+        c[C_ETA_M] = eta_m;
+        c[C_KB] = K_g * k_m / r_mp;
+        c[C_MTG] = (m_c + m_p) * g;        // f_normal :202
+        c[C_MPL2] = m_p * l_p / 2.0f;
+        c[C_MU] = mu_c;
+        c[C_M00] = m_p + J_eq;             // mass matrix :211-216
+        c[C_MPL] = m_p * l_p;
+        c[C_M11] = J_pole + m_p * l_p * l_p;
+        c[C_BEQ] = B_eq;
+        c[C_BP] = B_p;
+        c[C_MPLG] = m_p * l_p * g;
+        c[C_TH_NEG] = p[15];
+        c[C_TH_POS] = p[16];
+        c[C_XMAX] = l_rail / 2.0f - 0.15f;  // _create_spaces :546-551, _x_buffer :77
+        c[C_XDMAX] = l_rail;
+    }
+    __device__ static void state_bounds(const float* c, float* lo, float* hi) {
+        hi[0] = c[C_XMAX]; hi[1] = PI4_F; hi[2] = c[C_XDMAX]; hi[3] = PI20_F;
+        for (int j = 0; j < 4; ++j) lo[j] = -hi[j];
+    }
+    __device__ static void act_bounds(const float*, float* lo, float* hi) { hi[0] = 6.0f; lo[0] = -6.0f; }  // MAX_ACT_QCP
+    // one evaluation of QCartPoleSim._dynamics (:166-230) on the augmented state y = [x, th, x_dot, th_dot], action u
+    __device__ static void f_dyn(const Task& T, const float* c, const float* y, float u, float thdd_prev, float* k,
+                                 float& thdd_out) {
+        float th = y[1], x_dot = y[2], th_dot = y[3];
+        float sin_th, cos_th;
+        sincosf(th, &sin_th, &cos_th);
+        bool simple = (T.flags & 1) != 0;
+        if (!simple && c[C_TH_NEG] <= u && u <= c[C_TH_POS]) u = 0.f;  // dead zone :188-192
+        float f_act = c[C_KA] * (c[C_ETA_M] * u - c[C_KB] * x_dot);
+        float f_tot = f_act;
+        if (!simple) {
+            float f_normal = c[C_MTG] - c[C_MPL2] * (sin_th * thdd_prev + cos_th * th_dot * th_dot);
+            float f_c = f_normal < 0.f ? 0.f : c[C_MU] * f_normal * sgnf(x_dot);
+            f_tot = f_act - f_c;
+        }
+        float M01 = c[C_MPL] * cos_th;
+        float r0 = f_tot - c[C_BEQ] * x_dot - c[C_MPL] * sin_th * th_dot * th_dot;
+        float r1 = -c[C_BP] * th_dot - c[C_MPLG] * sin_th;
+        // np.linalg.solve on the SPD 2x2 -> closed form
+        float inv_det = 1.0f / (c[C_M00] * c[C_M11] - M01 * M01);
+        float x_ddot = (c[C_M11] * r0 - M01 * r1) * inv_det;
+        float th_ddot = (c[C_M00] * r1 - M01 * r0) * inv_det;
+        k[0] = x_dot + x_ddot * T.dt;  // already Euler-advanced velocities as position derivative (Q6, :227-230)
+        k[1] = th_dot + th_ddot * T.dt;
+        k[2] = x_ddot;
+        k[3] = th_ddot;
+        thdd_out = th_ddot;
+    }
+    __device__ static void dynamics(const Task& T, const float* c, float* s, float* h, const float* act) {
+        // rk4 (:591-655) over [x, th, x_dot, th_dot, u]; u has zero derivative; th_ddot chained through the stages.
+        // The four stage vectors live in VGPRs (16 floats per lane): there is no cross-lane reuse to stage in LDS.
+        float u = act[0], dt = T.dt, dt2 = dt / 2.0f;
+        float k1[4], k2[4], k3[4], k4[4], y[4], a1, a2, a3, a4;
+        f_dyn(T, c, s, u, h[0], k1, a1);
+        for (int j = 0; j < 4; ++j) y[j] = s[j] + dt2 * k1[j];
+        f_dyn(T, c, y, u, a1, k2, a2);
+        for (int j = 0; j < 4; ++j) y[j] = s[j] + dt2 * k2[j];
+        f_dyn(T, c, y, u, a2, k3, a3);
+        for (int j = 0; j < 4; ++j) y[j] = s[j] + dt * k3[j];
+        f_dyn(T, c, y, u, a3, k4, a4);
+        for (int j = 0; j < 4; ++j) s[j] = s[j] + dt / 6.0f * (k1[j] + 2.0f * k2[j] + 2.0f * k3[j] + k4[j]);
+        h[0] = (a1 + a2 + a3 + a4) / 4.0f;  // mean of the stage th_ddots (:652)
+    }
+    __device__ static void observe(const float* s, float* o) {  // :107-108
+        o[0] = s[0];
+        sincosf(s[1], &o[1], &o[2]);
+        o[3] = s[2];
+        o[4] = s[3];
+    }
+    __device__ static void sample_init(const Task& T, const float*, Rng& g, float* init) {  // :552-560
+        float hi[4];
+        if (T.wild_init == 0) { hi[0] = 0.25f; hi[1] = PI_F; hi[2] = 0.8f; hi[3] = PI_F; }
+        else if (T.wild_init == 1) { hi[0] = 0.02f; hi[1] = 2.0f / 180.0f * PI_F; hi[2] = 0.f; hi[3] = 1.0f / 180.0f * PI_F; }
+        else { hi[0] = 0.02f; hi[1] = PI_F; hi[2] = 0.f; hi[3] = 1.0f / 180.0f * PI_F; }
+        for (int j = 0; j < 4; ++j) init[j] = g.uniform(-hi[j], hi[j]);
+    }
+    __device__ static void state_from_init(const float* init, float* s) {
+        for (int j = 0; j < 4; ++j) s[j] = init[j];
+    }
+    __device__ static void init_hidden(const Task&, const float*, const float*, const float*, float* h, bool) {
+        h[0] = 0.f;  // reset(): self._th_ddot = 0.0 (:103)
+    }
+};
+
+// =================================================================================================== QBB
+// QBallBalancerKin.__call__ (quanser_ball_balancer.py:375-444, Q8): 100 iterations of torch-fp32 SGD(lr .01, mom .9) on
+// the rod tip, gradient written out the way autograd evaluates it (pow_backward g*(2x), sqrt backward g/(2*result))
+__device__ inline float qbb_ik(float th, float r, float l) {
+    const float d = 0.10f, lr = 0.01f, mom = 0.9f;
+    float t0 = r, t1 = l;
+    float sn, cs;
+    sincosf(th, &sn, &cs);
+    float rc = r * cs, rs = r * sn;
+    float b0 = 0.f, b1 = 0.f;
+    for (int it = 0; it < 100; ++it) {
+        float dx = t0 - rc, dy = t1 - rs;
+        float rod = sqrtf(dx * dx + dy * dy);
+        float ex = t0 - r - l, ey = t1 - d;
+        float half = sqrtf(ex * ex + ey * ey);
+        float gu1 = (2.0f * (rod - d)) / (2.0f * rod);
+        float gu2 = (2.0f * (half - l)) / (2.0f * half);
+        float g0 = gu1 * (2.0f * dx) + gu2 * (2.0f * ex);
+        float g1 = gu1 * (2.0f * dy) + gu2 * (2.0f * ey);
+        if (it == 0) { b0 = g0; b1 = g1; }
+        else { b0 = b0 * mom + g0; b1 = b1 * mom + g1; }
+        t0 -= lr * b0;
+        t1 -= lr * b1;
+    }
+    return PI_F / 2.0f - atan2f(r + l - t0, t1 - d);
+}
+
+// QBallBalancerSim, P/environments/pysim/quanser_ball_balancer.py:49-337
+struct Qbb {
+    static constexpr int S = 8, A = 2, O = 8, H = 2, I = 4, P = 20, K = 19, KS = 17;
+    static constexpr int REW = REW_SCALED_EXP, RADIAL = -1;
+    static constexpr bool HAS_FINAL = false;
+    enum { C_AM, C_BEQV, C_JEQ, C_CKIN, C_OFFX, C_OFFY, C_TXP, C_TXN, C_TYP, C_TYN, C_BDR2, C_JBR, C_MR2, C_CKMGR2,
+           C_ZETA, C_XMAX, C_CMAX, C_IK_X0, C_IK_Y0 };
+    static constexpr int CMAX = C_CMAX;
+    __device__ static void calc_consts(const Task& T, const float* p, float* c) {  // _calc_constants :204-223
+        float g = p[0], m_ball = p[1], r_ball = p[2], l_plate = p[3], r_arm = p[4], K_g = p[5], eta_g = p[6],
+              J_l = p[7], J_m = p[8], k_m = p[9], R_m = p[10], eta_m = p[11], B_eq = p[12], ball_damping = p[13];
+        float J_ball = 2.0f / 5 * m_ball * r_ball * r_ball;
+        float c_kin = 2.0f * r_arm / l_plate;
+        float r2 = r_ball * r_ball;
+        c[C_AM] = eta_g * K_g * eta_m * k_m / R_m;
+        c[C_BEQV] = eta_g * K_g * K_g * eta_m * k_m * k_m / R_m + B_eq;
+        c[C_JEQ] = eta_g * K_g * K_g * J_m + J_l;
+        c[C_CKIN] = c_kin;
+        c[C_OFFX] = p[18]; c[C_OFFY] = p[19];
+        c[C_TXP] = p[14]; c[C_TXN] = p[15]; c[C_TYP] = p[16]; c[C_TYN] = p[17];
+        c[C_BDR2] = ball_damping * r2;            // friction term :313
+        c[C_JBR] = J_ball * r_ball;               // plate influence :314
+        c[C_MR2] = m_ball * r2;                   // centripetal :315
+        c[C_CKMGR2] = c_kin * m_ball * g * r2;    // gravity :316
+        c[C_ZETA] = m_ball * r2 + J_ball;
+        c[C_XMAX] = l_plate / 2.0f;               // _create_spaces :97-107
+        float smax[8] = {PI_4_F, PI_4_F, c[C_XMAX], c[C_XMAX], PI5_F, PI5_F, 0.5f, 0.5f};
+        float mc = 0.f;
+        for (int j = 0; j < 8; ++j) mc += smax[j] * (T.qd[j] * smax[j]);
+        float ma = 0.f;
+        for (int j = 0; j < 2; ++j) ma += 3.0f * (T.rd[j] * 3.0f);  // MAX_ACT_QBB
+        c[C_CMAX] = 9.210340371976182f / (mc + ma);
+        // plate angles of the init-space reset (servo angles 0): depend on the params only -> cached (reset :238-242)
+        bool simple = (T.flags & 1) != 0;
+        c[C_IK_X0] = simple ? 0.f : qbb_ik(0.f + c[C_OFFX], r_arm, l_plate / 2.0f);
+        c[C_IK_Y0] = simple ? 0.f : qbb_ik(0.f + c[C_OFFY], r_arm, l_plate / 2.0f);
+    }
+    __device__ static void state_bounds(const float* c, float* lo, float* hi) {
+        hi[0] = PI_4_F; hi[1] = PI_4_F; hi[2] = c[C_XMAX]; hi[3] = c[C_XMAX];
+        hi[4] = PI5_F; hi[5] = PI5_F; hi[6] = 0.5f; hi[7] = 0.5f;
+        for (int j = 0; j < 8; ++j) lo[j] = -hi[j];
+    }
+    __device__ static void act_bounds(const float*, float* lo, float* hi) {
+        hi[0] = hi[1] = 3.0f; lo[0] = lo[1] = -3.0f;  // MAX_ACT_QBB
+    }
+    __device__ static void dynamics(const Task& T, const float* c, float* s, float* h, const float* act) {  // :247-330
+        bool simple = (T.flags & 1) != 0;
+        float a0 = act[0], a1 = act[1];
+        if (!simple && c[C_TXN] <= a0 && a0 <= c[C_TXP]) a0 = 0.f;  // dead zones :261-264
+        if (!simple && c[C_TYN] <= a1 && a1 <= c[C_TYP]) a1 = 0.f;
+        float th_x = s[0] + c[C_OFFX], th_y = s[1] + c[C_OFFY];
+        float x = s[2], y = s[3], th_x_dot = s[4], th_y_dot = s[5], x_dot = s[6], y_dot = s[7];
+        float th_x_ddot = (c[C_AM] * a0 - c[C_BEQV] * th_x_dot) / c[C_JEQ];
+        float th_y_ddot = (c[C_AM] * a1 - c[C_BEQV] * th_y_dot) / c[C_JEQ];
+        float sx, cx, sy, cy, sa, ca, sb, cb;
+        sincosf(th_x, &sx, &cx);
+        sincosf(th_y, &sy, &cy);
+        sincosf(h[0], &sa, &ca);
+        sincosf(h[1], &sb, &cb);
+        float ck = c[C_CKIN];
+        float a_dot = ck * th_x_dot * cx / ca;
+        float b_dot = ck * -th_y_dot * cy / cb;  // cos(-th_y) = cos(th_y)
+        float x_ddot, y_ddot;
+        if (simple) {
+            x_ddot = c[C_CKMGR2] * sx / c[C_ZETA];
+            y_ddot = c[C_CKMGR2] * sy / c[C_ZETA];
+        } else {
+            float a_ddot = 1.0f / ca * (ck * (th_x_ddot * cx - th_x_dot * th_x_dot * sx) + a_dot * a_dot * sa);
+            // -(-th_y_dot)^2 * sin(-th_y) = + th_y_dot^2 * sin(th_y)
+            float b_ddot = 1.0f / cb * (ck * (-th_y_ddot * cy + th_y_dot * th_y_dot * sy) + b_dot * b_dot * sb);
+            x_ddot = (-c[C_BDR2] * x_dot - c[C_JBR] * a_ddot + c[C_MR2] * x * a_dot * a_dot + c[C_CKMGR2] * sx) / c[C_ZETA];
+            y_ddot = (-c[C_BDR2] * y_dot - c[C_JBR] * b_ddot + c[C_MR2] * y * b_dot * b_dot + c[C_CKMGR2] * sy) / c[C_ZETA];
+        }
+        float dt = T.dt;
+        s[4] += th_x_ddot * dt; s[5] += th_y_ddot * dt; s[6] += x_ddot * dt; s[7] += y_ddot * dt;  // symplectic Euler
+        s[0] += s[4] * dt; s[1] += s[5] * dt; s[2] += s[6] * dt; s[3] += s[7] * dt;
+        h[0] += a_dot * dt;  // forward Euler on the plate angles :330
+        h[1] += b_dot * dt;
+    }
+    __device__ static void observe(const float* s, float* o) {
+        for (int j = 0; j < 8; ++j) o[j] = s[j];
+    }
+    __device__ static void sample_init(const Task&, const float* c, Rng& g, float* init) {  // :108-117, polar.py:108-113
+        float l2 = c[C_XMAX];
+        float r = g.uniform(0.75f * l2, 0.8f * l2);
+        float phi = g.uniform(-PI_F, PI_F);
+        float sp, cp;
+        sincosf(phi, &sp, &cp);
+        init[0] = r * cp;
+        init[1] = r * sp;
+        init[2] = g.uniform(-0.025f, 0.025f);
+        init[3] = g.uniform(-0.025f, 0.025f);
+    }
+    __device__ static void state_from_init(const float* init, float* s) {  // _state_from_init :225-229
+        s[0] = s[1] = s[4] = s[5] = 0.f;
+        s[2] = init[0]; s[3] = init[1]; s[6] = init[2]; s[7] = init[3];
+    }
+    // reset(): plate_angs = IK(th + offset) (:231-245). From the init space the servo angles are 0 -> cached constants;
+    // a full-state init with non-zero servo angles runs the IK (needs arm_radius / plate_length from the raw params).
+    __device__ static void init_hidden(const Task& T, const float* c, const float* p, const float* s, float* h,
+                                       bool full_state) {
+        if ((T.flags & 1) != 0) { h[0] = h[1] = 0.f; return; }
+        if (!full_state || (s[0] == 0.f && s[1] == 0.f)) { h[0] = c[C_IK_X0]; h[1] = c[C_IK_Y0]; return; }
+        h[0] = qbb_ik(s[0] + c[C_OFFX], p[4], p[3] / 2.0f);
+        h[1] = qbb_ik(s[1] + c[C_OFFY], p[4], p[3] / 2.0f);
+    }
+};
+
+}  // namespace vs

@@ -1,0 +1,359 @@
+"""
+Batched, device-resident environment: the Python face of one libvecsim handle (include/vecsim.h).
+
+``VecSimEnv`` is the vectorised counterpart of Pyrado's ``SimPyEnv`` (P/environments/pysim/base.py:43-289): N independent
+environment instances of one family, one per wavefront lane on an MI355X.  Control-path data (domain parameters, explicit
+initial states, masks) are NumPy arrays; hot-path data (actions in, observations / rewards / done flags out) are
+device buffers exposed zero-copy as torch tensors.  There is no CPU implementation behind this class.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _lib as L
+from .exceptions import ShapeErr, TypeErr, ValueErr
+
+_BUF_DTYPES = {
+    L.VS_STATE: ("f4", "S"), L.VS_OBS: ("f4", "O"), L.VS_REW: ("f4", 1), L.VS_DONE: ("u1", 1),
+    L.VS_HIDDEN: ("f4", "H"), L.VS_STEPCOUNT: ("i4", 1), L.VS_ERRFLAG: ("u1", 1), L.VS_RETURNS: ("f4", 1),
+    L.VS_PARAMS: ("f4", "P"), L.VS_CONSTS: ("f4", "K"), L.VS_FAILED: ("u1", 1),
+}
+
+
+class _DevArray:
+    """Minimal __cuda_array_interface__ carrier so torch.as_tensor() can wrap a libvecsim buffer without a copy."""
+
+    def __init__(self, ptr, shape, typestr, owner):
+        self.__cuda_array_interface__ = dict(shape=tuple(shape), typestr=typestr, data=(int(ptr), False), version=2,
+                                             strides=None)
+        self._owner = owner  # keep the handle alive
+
+
+def env_dims(name):
+    lib = L.load()
+    vals = [C.c_int() for _ in range(7)]
+    rc = lib.vs_env_dims(L.ENV_TYPES[name], *[C.byref(v) for v in vals])
+    if rc != 0:
+        raise ValueErr(msg=f"unknown env type {name}")
+    return dict(zip("SAOPHIK", (v.value for v in vals)))
+
+
+def param_names(name):
+    lib = L.load()
+    t = L.ENV_TYPES[name]
+    return [lib.vs_param_name(t, i).decode() for i in range(env_dims(name)["P"])]
+
+
+def nominal_params(name, long=False):
+    lib = L.load()
+    d = env_dims(name)
+    out = (C.c_float * d["P"])()
+    lib.vs_nominal_params(L.ENV_TYPES[name], L.VS_FLAG_LONG_POLE if long else 0, out)
+    return np.array(out[:], dtype=np.float32)
+
+
+class VecSimEnv:
+    """N environments of one Pyrado pysim family on one GPU."""
+
+    def __init__(self, name, n_envs, dt, max_steps=math.inf, task_args=None, device=0, simple_dynamics=False,
+                 long=False, wild_init="True"):
+        if name not in L.ENV_TYPES:
+            raise ValueErr(msg=f"unknown environment name {name!r}; expected one of {sorted(L.ENV_TYPES)}")
+        if not isinstance(dt, (int, float)):
+            raise TypeErr(given=dt, expected_type=(int, float))  # Env.__init__, P/environments/base.py:56-57
+        if dt < 0:
+            raise ValueErr(given=dt, ge_constraint="0")
+        if max_steps < 1:
+            raise ValueErr(given=max_steps, ge_constraint="1")
+        if not (isinstance(task_args, dict) or task_args is None):
+            raise TypeErr(given=task_args, expected_type=dict)  # P/environments/pysim/base.py:70-71
+        self._lib = L.load()
+        self.name = name
+        self.n_envs = int(n_envs)
+        self.dt = float(dt)
+        self.max_steps = max_steps
+        self.device = int(device)
+        self.dims = env_dims(name)
+        self.param_names = param_names(name)
+        self._flags = (L.VS_FLAG_SIMPLE_DYNAMICS if simple_dynamics else 0) | (L.VS_FLAG_LONG_POLE if long else 0)
+        cfg = L.TaskCfg()
+        cfg.use_defaults = 1
+        cfg.flags = self._flags
+        cfg.wild_init = {"True": 0, "False": 1}.get(str(wild_init), 2)
+        if task_args:
+            cfg.use_defaults = 0
+            des, qd, rd = self.default_task(name)
+            if "state_des" in task_args:
+                des = np.asarray(task_args["state_des"], dtype=np.float64).reshape(-1)
+            if "Q" in task_args:
+                qd = self._diag(task_args["Q"], "Q")
+            if "R" in task_args:
+                rd = self._diag(task_args["R"], "R")
+            if des.shape != (self.dims["S"],) or qd.shape != (self.dims["S"],) or rd.shape != (self.dims["A"],):
+                raise ShapeErr(msg="task_args state_des / Q / R do not match the state / action dimensions")
+            cfg.state_des[: des.size] = list(map(float, des))
+            cfg.q_diag[: qd.size] = list(map(float, qd))
+            cfg.r_diag[: rd.size] = list(map(float, rd))
+        self._cfg = cfg
+        h = C.c_void_p()
+        ms = 0 if max_steps == math.inf else int(max_steps)
+        rc = self._lib.vs_create(L.ENV_TYPES[name], self.n_envs, self.dt, ms, self.device, C.byref(cfg), C.byref(h))
+        if rc != 0:
+            raise RuntimeError(f"vs_create failed ({rc}): {self._lib.vs_last_error(None).decode()}")
+        self._h = h
+        self.ld = int(self._lib.vs_ld(h))
+        self._traj_cap = 0
+
+    # ------------------------------------------------------------------------------------------------ helpers
+    @staticmethod
+    def default_task(name):
+        """Reference defaults of _create_task (state_des, diag Q, diag R) for each env."""
+        pi = np.pi
+        return {
+            "omo": (np.zeros(2), np.array([1e1, 1e-2]), np.array([1e-6])),
+            "bob": (np.zeros(4), np.array([1e5, 1e3, 1e3, 1e2]), np.array([1.0])),
+            "qq-su": (np.array([0.0, pi, 0.0, 0.0]), np.array([1.0, 1.0, 2e-2, 5e-3]), np.array([4e-3])),
+            "qcp-su": (np.array([0.0, pi, 0.0, 0.0]), np.array([3e-1, 5e-1, 5e-3, 1e-3]), np.array([1e-3])),
+            "qbb": (np.zeros(8), np.array([1e0, 1e0, 5e3, 5e3, 1e-2, 1e-2, 5e-1, 5e-1]), np.array([1e-2, 1e-2])),
+        }[name]
+
+    @staticmethod
+    def _diag(M, label):
+        M = np.asarray(M, dtype=np.float64)
+        if M.ndim == 1:
+            return M
+        if np.count_nonzero(M - np.diag(np.diag(M))) != 0:
+            raise ValueErr(msg=f"The weight matrix {label} must be diagonal for the device kernels")
+        return np.diag(M).copy()
+
+    def _check(self, rc, what):
+        if rc != 0:
+            msg = self._lib.vs_last_error(self._h).decode()
+            if rc == L.VS_ERR_ARG:
+                raise ValueErr(msg=f"{what}: {msg}")
+            raise RuntimeError(f"{what} failed ({rc}): {msg}")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.vs_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _mask_arg(self, mask):
+        if mask is None:
+            return None, None
+        m = np.ascontiguousarray(np.asarray(mask).astype(np.uint8))
+        if m.shape != (self.n_envs,):
+            raise ShapeErr(given=m, expected_match=(self.n_envs,))
+        return m, m.ctypes.data_as(C.c_void_p)
+
+    # ------------------------------------------------------------------------------------------------ domain parameters
+    def _params_matrix(self, params):
+        """dict name -> scalar/array [N]  or array [N, P]  ->  f32 [P][N] (unspecified names keep the current value)"""
+        P = self.dims["P"]
+        if isinstance(params, dict):
+            unknown = [k for k in params if k not in self.param_names]
+            if unknown:
+                raise ValueErr(msg=f"unsupported domain parameter(s) {unknown} for env {self.name}")
+            cur = self.get(L.VS_PARAMS).T.copy()  # [P][N]
+            for k, v in params.items():
+                cur[self.param_names.index(k)] = np.broadcast_to(np.asarray(v, dtype=np.float32).reshape(-1), (self.n_envs,)) \
+                    if np.size(v) in (1, self.n_envs) else self._bad_shape(v)
+            return np.ascontiguousarray(cur, dtype=np.float32)
+        arr = np.asarray(params, dtype=np.float32)
+        if arr.shape != (self.n_envs, P):
+            raise ShapeErr(given=arr, expected_match=(self.n_envs, P))
+        return np.ascontiguousarray(arr.T)
+
+    def _bad_shape(self, v):
+        raise ShapeErr(given=np.asarray(v), expected_match=(self.n_envs,))
+
+    def set_params(self, params, mask=None):
+        """The `domain_param` setter for all (or the masked) envs: params -> _calc_constants -> spaces -> task.reset."""
+        mat = self._params_matrix(params)
+        m, mp = self._mask_arg(mask)
+        self._check(self._lib.vs_set_params(self._h, mat.ctypes.data_as(C.c_void_p), self.n_envs, mp), "vs_set_params")
+
+    def set_params_uniform(self, params=None):
+        vec = nominal_params(self.name, long=bool(self._flags & L.VS_FLAG_LONG_POLE))
+        if params:
+            for k, v in params.items():
+                if k not in self.param_names:
+                    raise ValueErr(msg=f"unsupported domain parameter {k!r} for env {self.name}")
+                vec[self.param_names.index(k)] = float(v)
+        arr = (C.c_float * len(vec))(*map(float, vec))
+        self._check(self._lib.vs_set_params_uniform(self._h, arr), "vs_set_params_uniform")
+
+    def _specs(self, specs):
+        """specs: iterable of (name, kind 'normal'|'uniform', mean, spread, clip_lo, clip_up) or objects with those attrs"""
+        rows = []
+        for s in specs:
+            if not isinstance(s, (tuple, list)):
+                kind = "normal" if hasattr(s, "std") else "uniform"
+                s = (s.name, kind, s.mean, getattr(s, "std", None) if kind == "normal" else s.halfspan,
+                     s.clip_lo, s.clip_up)
+            name, kind, mean, spread, lo, hi = s
+            if name not in self.param_names:
+                raise ValueErr(msg=f"unsupported domain parameter {name!r} for env {self.name}")
+            rows.append(L.DpSpec(self.param_names.index(name), L.VS_DP_NORMAL if kind == "normal" else L.VS_DP_UNIFORM,
+                                 float(mean), float(spread), float(lo), float(hi)))
+        arr = (L.DpSpec * max(len(rows), 1))(*rows)
+        return arr, len(rows)
+
+    def sample_params(self, specs, seed=0, mask=None):
+        arr, n = self._specs(specs)
+        m, mp = self._mask_arg(mask)
+        self._check(self._lib.vs_sample_params(self._h, arr, n, int(seed) & (2 ** 64 - 1), mp), "vs_sample_params")
+
+    def set_randomizer(self, specs):
+        arr, n = self._specs(specs or [])
+        self._check(self._lib.vs_set_randomizer(self._h, arr, n), "vs_set_randomizer")
+
+    # ------------------------------------------------------------------------------------------------ reset / step
+    def reset(self, init_state=None, mask=None, seed=0):
+        """SimPyEnv.reset for all (masked) envs. init_state: None (sample init space) or [N, I] / [N, S]."""
+        m, mp = self._mask_arg(mask)
+        ptr, full = None, 0
+        keep = None
+        if init_state is not None:
+            arr = np.asarray(init_state, dtype=np.float32)
+            if arr.ndim != 2 or arr.shape[0] != self.n_envs or arr.shape[1] not in (self.dims["I"], self.dims["S"]):
+                raise ShapeErr(given=arr, expected_match=(self.n_envs, self.dims["I"]))
+            full = int(arr.shape[1] == self.dims["S"])
+            keep = np.ascontiguousarray(arr.T)
+            ptr = keep.ctypes.data_as(C.c_void_p)
+        self._check(self._lib.vs_reset(self._h, ptr, self.n_envs, full, mp, int(seed) & (2 ** 64 - 1)), "vs_reset")
+
+    def set_auto_reset(self, on=True, seed=0):
+        self._check(self._lib.vs_set_auto_reset(self._h, int(bool(on)), int(seed) & (2 ** 64 - 1)), "vs_set_auto_reset")
+
+    def step(self, actions):
+        """One SimPyEnv.step for every env. `actions`: torch CUDA tensor of shape [N, A] (row-major policy output),
+        [A, N] / [A, ld] (struct-of-arrays) or [N] when A == 1."""
+        A = self.dims["A"]
+        if not hasattr(actions, "data_ptr"):
+            raise TypeErr(given=actions, expected_type="torch.Tensor (device)")
+        if not actions.is_cuda or str(actions.dtype) != "torch.float32":
+            raise TypeErr(msg="actions must be a float32 tensor on the GPU")
+        shp = tuple(actions.shape)
+        if shp == (self.n_envs, A) or (A == 1 and shp == (self.n_envs,)):
+            es, ds = (actions.stride(0), actions.stride(1)) if actions.dim() == 2 else (actions.stride(0), 0)
+        elif len(shp) == 2 and shp[0] == A and shp[1] in (self.n_envs, self.ld):
+            es, ds = actions.stride(1), actions.stride(0)
+        else:
+            raise ShapeErr(given=actions, expected_match=(self.n_envs, A))
+        self._check(self._lib.vs_step(self._h, C.c_void_p(actions.data_ptr()), es, ds), "vs_step")
+
+    def step_random(self, k_steps=1, seed=0, record=False):
+        if record and k_steps > self._traj_cap:
+            self._check(self._lib.vs_set_traj_capacity(self._h, int(k_steps)), "vs_set_traj_capacity")
+            self._traj_cap = int(k_steps)
+        self._check(self._lib.vs_step_random(self._h, int(seed) & (2 ** 64 - 1), int(k_steps), int(bool(record))),
+                    "vs_step_random")
+
+    def sync(self):
+        self._check(self._lib.vs_sync(self._h), "vs_sync")
+
+    def use_stream(self, stream_ptr):
+        self._check(self._lib.vs_set_stream(self._h, C.c_void_p(stream_ptr) if stream_ptr else None), "vs_set_stream")
+
+    # ------------------------------------------------------------------------------------------------ data access
+    def _rows(self, which):
+        dt, rows = _BUF_DTYPES[which]
+        return np.dtype(dt), (self.dims[rows] if isinstance(rows, str) else rows)
+
+    def get(self, which):
+        """Host copy of a per-env buffer as [N, dim] (or [N] for scalar buffers)."""
+        dt, rows = self._rows(which)
+        if rows == 0:
+            return np.zeros((self.n_envs, 0), dtype=dt)
+        buf = np.empty((rows, self.ld), dtype=dt)
+        self._check(self._lib.vs_copy_to_host(self._h, which, buf.ctypes.data_as(C.c_void_p)), "vs_copy_to_host")
+        out = buf[:, : self.n_envs]
+        if isinstance(_BUF_DTYPES[which][1], int):
+            return out[0].copy()
+        return np.ascontiguousarray(out.T)
+
+    def put(self, which, value):
+        """`state` / hidden / step-count assignment from the host ([N, dim])."""
+        dt, rows = self._rows(which)
+        if rows == 0:
+            return
+        val = np.asarray(value, dtype=dt)
+        if val.ndim == 1:
+            val = val[:, None]
+        if val.shape != (self.n_envs, rows):
+            raise ShapeErr(given=val, expected_match=(self.n_envs, rows))
+        buf = np.zeros((rows, self.ld), dtype=dt)
+        buf[:, : self.n_envs] = val.T
+        buf[:, self.n_envs:] = val.T[:, -1:]
+        self._check(self._lib.vs_copy_from_host(self._h, which, buf.ctypes.data_as(C.c_void_p)), "vs_copy_from_host")
+
+    def tensor(self, which):
+        """Zero-copy torch view [rows, ld] of a device buffer (rows = dim of the buffer)."""
+        import torch
+
+        dt, rows = self._rows(which)
+        ptr = self._lib.vs_get(self._h, which)
+        if not ptr or rows == 0:
+            raise ValueErr(msg=f"buffer {which} is not available")
+        arr = _DevArray(ptr, (rows, self.ld), {"f4": "<f4", "u1": "|u1", "i4": "<i4"}[dt.str[1:]], self)
+        return torch.as_tensor(arr, device=f"cuda:{self.device}")
+
+    def traj(self, k_steps):
+        """Host copies of the recorded trajectory buffers of the last step_random(record=True): dict of [T, N, dim]"""
+        import torch
+
+        out = {}
+        for key, which, rows, dt in (("obs", L.VS_TRAJ_OBS, self.dims["O"], "<f4"), ("act", L.VS_TRAJ_ACT, self.dims["A"], "<f4"),
+                                     ("rew", L.VS_TRAJ_REW, 1, "<f4"), ("done", L.VS_TRAJ_DONE, 1, "|u1")):
+            ptr = self._lib.vs_get(self._h, which)
+            arr = _DevArray(ptr, (self._traj_cap, rows, self.ld), dt, self)
+            self.sync()
+            t = torch.as_tensor(arr, device=f"cuda:{self.device}")[:k_steps, :, : self.n_envs].permute(0, 2, 1)
+            t = t.cpu().numpy()
+            out[key] = t if rows > 1 or key in ("obs", "act") else t[..., 0]
+        return out
+
+    def episodes(self, clear=True):
+        """Completed episodes since the last clear: (returns [M], lengths [M], env index [M])."""
+        cnt = np.zeros(1, dtype=np.uint32)
+        self._check(self._lib.vs_copy_to_host(self._h, L.VS_EP_COUNT, cnt.ctypes.data_as(C.c_void_p)), "vs_copy_to_host")
+        cap = max(self.ld, 1 << 16)
+        m = int(min(cnt[0], cap))
+        ret = np.empty(cap, dtype=np.float32)
+        ln = np.empty(cap, dtype=np.int32)
+        ix = np.empty(cap, dtype=np.int32)
+        for which, buf in ((L.VS_EP_RETURNS, ret), (L.VS_EP_LENGTHS, ln), (L.VS_EP_ENVIDX, ix)):
+            self._check(self._lib.vs_copy_to_host(self._h, which, buf.ctypes.data_as(C.c_void_p)), "vs_copy_to_host")
+        if clear:
+            self._check(self._lib.vs_clear_episodes(self._h), "vs_clear_episodes")
+        return ret[:m].copy(), ln[:m].copy(), ix[:m].copy()
+
+    def error_count(self):
+        return int(self._lib.vs_error_count(self._h))
+
+    def raise_on_error(self):
+        """The reference raises pyrado.ValueErr on a NaN action/state (P/spaces/box.py:142-146, rollout.py:193-230)."""
+        n = self.error_count()
+        if n > 0:
+            raise ValueErr(msg=f"At least one value is NaN! ({n} environment(s) flagged)")
+
+    def time_step_kernel(self, iters=100, actions=None, k_steps=1, record=False):
+        """Average device time [ms] per launch of the step kernel (hipEvents on the kernel's stream)."""
+        ms = C.c_float()
+        if actions is not None:
+            A = self.dims["A"]
+            es, ds = (actions.stride(0), actions.stride(1)) if actions.dim() == 2 and actions.shape[0] != A else \
+                (actions.stride(-1), actions.stride(0) if actions.dim() == 2 else 0)
+            rc = self._lib.vs_time_step_kernel(self._h, 0, C.c_void_p(actions.data_ptr()), es, ds, 0, 0, int(iters), C.byref(ms))
+        else:
+            rc = self._lib.vs_time_step_kernel(self._h, 1, None, 0, 0, int(k_steps), int(bool(record)), int(iters), C.byref(ms))
+        self._check(rc, "vs_time_step_kernel")
+        return float(ms.value)

@@ -1,0 +1,509 @@
+"""
+GPU parity tests proper: the HIP path, called through the C-ABI (ctypes -> libvecsim.so), against
+  (1) the committed golden vectors the reference produced (tests/golden/*.npz),
+  (2) the oracle (oracle/cpu_ref.py, fp64) on identical seeded inputs,
+  (3) size-independent properties at BASELINE.json's full sizes.
+
+Tolerances (north_star: "done masks bit-exact, state trajectories within 1e-5 relative fp32"):
+  states / observations / hidden : |got - ref| <= 1e-5 * |ref| + ATOL_S   (one step from identical inputs)
+  rewards                        : |got - ref| <= 2e-4 * |ref| + 1e-12    (exp(-cost), cost up to a few hundred)
+  done / failed masks            : bit-exact wherever the fp64 next state is further than 1e-5 (relative) from a bound,
+                                   and ALWAYS bit-exact w.r.t. the kernel's own fp32 next state.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import cpu_ref
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+ENVS = ["omo", "bob", "qq-su", "qcp-su", "qbb"]
+KW = {"omo": dict(dt=0.02, max_steps=300), "bob": dict(dt=0.01, max_steps=500), "qq-su": dict(dt=0.004, max_steps=4000),
+      "qcp-su": dict(dt=0.002, max_steps=8000), "qbb": dict(dt=0.01, max_steps=500)}
+RTOL_S, ATOL_S = 1e-5, 2e-6
+RTOL_R, ATOL_R = 2e-4, 1e-12
+
+
+@pytest.fixture(scope="module")
+def vs():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import simurlacra_amd
+
+    return simurlacra_amd
+
+
+def load(golden_dir, kind, name):
+    return np.load(os.path.join(golden_dir, f"{kind}_{name.replace('-', '_')}.npz"))
+
+
+def f32(x):
+    return np.asarray(x, dtype=np.float32)
+
+
+def dev(x):
+    return torch.from_numpy(np.ascontiguousarray(f32(x))).cuda()
+
+
+def bound_margin(ref, nstate, params):
+    slo, shi, _, _ = ref.bounds(params)
+    scale = np.maximum(np.abs(shi), 1e-12)
+    return np.minimum(np.abs(nstate - slo), np.abs(nstate - shi)) / scale
+
+
+def check_step(env, L, ref, params, state, hidden, act, curr_step, exp, yielded=None):
+    """exp: dict with state/obs/rew/done(/hidden) from the reference or the oracle (fp64)"""
+    got_state = env.get(L.VS_STATE).astype(np.float64)
+    np.testing.assert_allclose(got_state, exp["state"], rtol=RTOL_S, atol=ATOL_S)
+    np.testing.assert_allclose(env.get(L.VS_OBS), exp["obs"], rtol=RTOL_S, atol=ATOL_S)
+    np.testing.assert_allclose(env.get(L.VS_REW), exp["rew"], rtol=RTOL_R, atol=ATOL_R)
+    if ref.H:
+        np.testing.assert_allclose(env.get(L.VS_HIDDEN), exp["hidden"], rtol=1e-4, atol=1e-4 if ref.name == "qcp-su" else 2e-6)
+    got_done = env.get(L.VS_DONE).astype(bool)
+    margin = bound_margin(ref, exp["state"], params).min(axis=1)
+    far = margin > 1e-5
+    assert np.array_equal(got_done[far], np.asarray(exp["done"], dtype=bool)[far])
+    assert (~far).sum() <= max(2, 0.01 * far.size)
+    # bit-exact w.r.t. the kernel's own fp32 state: done == any(s' < lo32 | s' > hi32) | timeout
+    slo, shi, _, _ = ref.bounds(f32(env.get(L.VS_PARAMS)).astype(np.float64))
+    s32 = env.get(L.VS_STATE)
+    lo32, hi32 = cpu_ref.make_ref(ref.name, ref.dt, ref.max_steps, dtype=np.float32).bounds(env.get(L.VS_PARAMS))[:2]
+    failed = ((s32 < lo32) | (s32 > hi32)).any(axis=1)
+    timeout = (np.asarray(curr_step) + 1) >= ref.max_steps
+    assert np.array_equal(env.get(L.VS_FAILED).astype(bool), failed)
+    assert np.array_equal(got_done, failed | timeout)
+    assert np.array_equal(env.get(L.VS_STEPCOUNT), np.asarray(curr_step) + 1)
+
+
+def setup_lanes(env, L, params, state, hidden, curr_step):
+    env.set_params(f32(params))
+    env.reset(init_state=f32(state))  # full-state shape -> copied verbatim
+    if hidden.shape[1]:
+        env.put(L.VS_HIDDEN, f32(hidden))
+    env.put(L.VS_STEPCOUNT, np.asarray(curr_step, dtype=np.int32))
+
+
+@pytest.mark.parametrize("name", ENVS)
+def test_step_golden_cases(vs, golden_dir, name):
+    """single-step cases the reference produced, pushed through vs_set_params / vs_reset / vs_step"""
+    L = vs._lib
+    g = load(golden_dir, "step", name)
+    n = g["state"].shape[0]
+    env = vs.VecSimEnv(name, n, **KW[name])
+    ref = cpu_ref.make_ref(name, **KW[name])
+    setup_lanes(env, L, g["params"], g["state"], g["hidden"], g["curr_step"])
+    env.step(dev(g["act"]))
+    exp = dict(state=g["nstate"], obs=g["obs"], rew=g["rew"], done=g["done"], hidden=g["nhidden"])
+    check_step(env, L, ref, g["params"], g["state"], g["hidden"], g["act"], g["curr_step"], exp)
+    assert env.error_count() == 0
+    env.close()
+
+
+@pytest.mark.parametrize("name", ENVS)
+def test_step_along_golden_trajectories(vs, golden_dir, name):
+    """every (state_t, act_t) of the reference's trajectories as one lane: one-step parity on naturally reached states"""
+    L = vs._lib
+    g = load(golden_dir, "traj", name)
+    ref = cpu_ref.make_ref(name, **KW[name])
+    idx = [(i, t) for i in range(g["params"].shape[0]) for t in range(int(g["length"][i]))
+           if not (t > 0 and g["done"][i, t - 1])]  # steps after done carry the once-only final-reward flag
+    ii, tt = np.array(idx).T
+    env = vs.VecSimEnv(name, len(idx), **KW[name])
+    setup_lanes(env, L, g["params"][ii], g["state"][ii, tt], g["hidden"][ii, tt], tt)
+    env.step(dev(g["act"][ii, tt]))
+    exp = dict(state=g["state"][ii, tt + 1], obs=g["obs"][ii, tt], rew=g["rew"][ii, tt], done=g["done"][ii, tt],
+               hidden=g["hidden"][ii, tt + 1])
+    check_step(env, L, ref, g["params"][ii], None, None, None, tt, exp)
+    env.close()
+
+
+@pytest.mark.parametrize("name", ENVS)
+def test_closed_loop_short_horizon(vs, golden_dir, name):
+    """reset -> 30 steps on the device without host intervention vs the reference trajectory (chaos-limited tolerance)"""
+    L = vs._lib
+    g = load(golden_dir, "traj", name)
+    ref = cpu_ref.make_ref(name, **KW[name])
+    n = g["params"].shape[0]
+    env = vs.VecSimEnv(name, n, **KW[name])
+    env.set_params(f32(g["params"]))
+    env.reset(init_state=f32(g["init"]))
+    np.testing.assert_allclose(env.get(L.VS_STATE), g["state"][:, 0], rtol=RTOL_S, atol=ATOL_S)
+    if ref.H:
+        np.testing.assert_allclose(env.get(L.VS_HIDDEN), g["hidden"][:, 0], rtol=0, atol=5e-6)
+    T = int(min(30, g["length"].min()))
+    for t in range(T):
+        env.step(dev(g["act"][:, t]))
+        np.testing.assert_allclose(env.get(L.VS_REW), g["rew"][:, t], rtol=5e-3, atol=1e-9)
+    np.testing.assert_allclose(env.get(L.VS_STATE), g["state"][:, T], rtol=2e-4, atol=2e-5)
+    assert np.array_equal(env.get(L.VS_STEPCOUNT), np.full(n, T))
+    env.close()
+
+
+def test_omo_final_reward_once_and_stepping_after_done(vs, golden_dir):
+    """rollout(stop_on_done=False): the failure malus is paid once (final_reward.py:130-135); golden OMO trajectories
+    keep stepping after done"""
+    L = vs._lib
+    g = load(golden_dir, "traj", "omo")
+    n = g["params"].shape[0]
+    env = vs.VecSimEnv("omo", n, **KW["omo"])
+    env.set_params(f32(g["params"]))
+    env.reset(init_state=f32(g["init"]))
+    Lmin = int(g["length"].min())
+    saw_malus = False
+    for t in range(Lmin):
+        env.put(L.VS_STATE, f32(g["state"][:, t]))  # follow the reference states, keep the device's episode flags
+        env.step(dev(g["act"][:, t]))
+        np.testing.assert_allclose(env.get(L.VS_REW), g["rew"][:, t], rtol=RTOL_R, atol=1e-6)
+        assert np.array_equal(env.get(L.VS_DONE).astype(bool), g["done"][:, t])
+        saw_malus |= bool((g["rew"][:, t] < -900).any())
+    assert saw_malus
+    env.close()
+
+
+@pytest.mark.parametrize("name", ENVS)
+def test_reset_golden_cases(vs, golden_dir, name):
+    L = vs._lib
+    g = load(golden_dir, "reset", name)
+    ref = cpu_ref.make_ref(name, **KW[name])
+    for full in (False, True):
+        sel = np.where(g["full"] == full)[0]
+        env = vs.VecSimEnv(name, len(sel), **KW[name])
+        env.set_params(f32(g["params"][sel]))
+        init = g["init"][sel] if full else g["init"][sel][:, :ref.I]
+        env.reset(init_state=f32(init))
+        np.testing.assert_allclose(env.get(L.VS_STATE), g["state"][sel], rtol=1e-6, atol=1e-7)
+        obs = env.get(L.VS_OBS)
+        exp_obs = ref.observe(g["state"][sel])  # QCartPoleSim.reset returns the state (Q5); the device buffer holds observe()
+        np.testing.assert_allclose(obs, exp_obs, rtol=RTOL_S, atol=ATOL_S)
+        if ref.H:
+            np.testing.assert_allclose(env.get(L.VS_HIDDEN), g["hidden"][sel], rtol=0, atol=5e-6)
+        assert (env.get(L.VS_STEPCOUNT) == 0).all() and not env.get(L.VS_DONE).any()
+        # derived constants: bounds and c_max per env (Q11) -- checked through their effect below and directly here
+        if name in ("bob", "qbb"):
+            K = env.get(L.VS_CONSTS)
+            cmax_col = {"bob": 8, "qbb": 16}[name]
+            np.testing.assert_allclose(K[:, cmax_col], g["c_max"][sel], rtol=2e-6)
+        env.close()
+
+
+@pytest.mark.parametrize("name", ENVS)
+def test_oracle_parity_seeded_batch(vs, name):
+    """4096 seeded lanes (config-2 size), randomised params, random states/actions: HIP vs the fp64 oracle on the
+    SAME fp32-rounded inputs"""
+    L = vs._lib
+    n = 4096
+    rng = np.random.default_rng(42)
+    ref = cpu_ref.make_ref(name, **KW[name])
+    params = ref.nominal_params(n)
+    params *= 1 + 0.15 * rng.standard_normal(params.shape) * (params != 0)
+    for j, pn in enumerate(ref.param_names):
+        if pn.startswith("voltage_thold") and name != "qbb":
+            params[:, j] = np.where("neg" in pn, -1, 1) * rng.uniform(0, 0.4, n)
+        if pn.startswith("offset") or pn == "ang_offset":
+            params[:, j] = rng.uniform(-0.05, 0.05, n)
+    params = f32(params).astype(np.float64)
+    slo, shi, alo, ahi = ref.bounds(params)
+    state = f32(rng.uniform(-1, 1, slo.shape) * shi * np.where(rng.random(slo.shape) < 0.03, 1.001, 0.98)).astype(np.float64)
+    hidden = f32(rng.uniform(-1, 1, (n, ref.H)) * (100 if name == "qcp-su" else 0.3)).astype(np.float64)
+    act = f32(rng.uniform(-1.4, 1.4, alo.shape) * ahi).astype(np.float64)
+    curr = rng.integers(0, KW[name]["max_steps"], n)
+    curr[::17] = KW[name]["max_steps"] - 1
+    env = vs.VecSimEnv(name, n, **KW[name])
+    setup_lanes(env, L, params, state, hidden, curr)
+    env.step(dev(act))
+    exp = ref.step(state, hidden, act, params, curr)
+    check_step(env, L, ref, params, state, hidden, act, curr, exp)
+    env.close()
+
+
+def test_nan_action_sets_error_flag(vs):
+    """the reference raises pyrado.ValueErr on NaN (box.py:142-146); the kernel sets a sticky per-env flag instead"""
+    L = vs._lib
+    env = vs.VecSimEnv("qq-su", 300, **KW["qq-su"])
+    act = np.zeros((300, 1), dtype=np.float32)
+    act[[3, 77, 299]] = np.nan
+    env.step(dev(act))
+    flags = env.get(L.VS_ERRFLAG)
+    assert flags.sum() == 3 and flags[[3, 77, 299]].all()
+    assert env.error_count() == 3
+    with pytest.raises(vs.ValueErr):
+        env.raise_on_error()
+    env.step(dev(np.zeros((300, 1))))
+    assert env.error_count() == 3  # sticky until reset
+    env.reset()
+    assert env.error_count() == 0
+    env.close()
+
+
+@pytest.mark.parametrize("name", ENVS)
+def test_init_space_sampling(vs, name):
+    """vs_reset(init_state=NULL): device-side init_space.sample_uniform; test_init_spaces of the reference
+    (Pyrado/tests/test_environments.py:140-148): samples lie in the init space, states in the state space"""
+    L = vs._lib
+    n = 20000
+    env = vs.VecSimEnv(name, n, **KW[name])
+    ref = cpu_ref.make_ref(name, **KW[name])
+    params = ref.nominal_params(n)
+    env.reset(seed=5)
+    s = env.get(L.VS_STATE).astype(np.float64)
+    slo, shi, _, _ = ref.bounds(params)
+    assert ((s >= slo) & (s <= shi)).all()
+    eps = 1e-6
+    if name == "bob":
+        lo0, hi0 = ref.init_bounds(params, 0)
+        lo1, hi1 = ref.init_bounds(params, 1)
+        in0 = ((s >= lo0 - eps) & (s <= hi0 + eps)).all(axis=1)
+        in1 = ((s >= lo1 - eps) & (s <= hi1 + eps)).all(axis=1)
+        assert (in0 ^ in1).all() and 0.45 < in0.mean() < 0.55
+    elif name == "qbb":
+        lo, hi = ref.init_bounds(params)
+        r = np.hypot(s[:, 2], s[:, 3])
+        assert (r >= lo[:, 0] - eps).all() and (r <= hi[:, 0] + eps).all()
+        phi = np.arctan2(s[:, 3], s[:, 2])
+        assert abs(phi.mean()) < 0.06 and abs(phi.std() - np.pi / np.sqrt(3)) < 0.05
+        assert (np.abs(s[:, 6:]) <= 0.025 + eps).all() and (s[:, [0, 1, 4, 5]] == 0).all()
+    else:
+        lo, hi = ref.init_bounds(params)
+        assert ((s >= lo - eps) & (s <= hi + eps)).all()
+        span = (hi - lo)[0]
+        ok = span > 0
+        assert (np.abs(s.mean(axis=0) - ((lo + hi) / 2)[0])[ok] < 0.03 * span[ok]).all()
+        assert (np.abs(s.std(axis=0)[ok] - span[ok] / np.sqrt(12)) < 0.03 * span[ok]).all()
+    # same seed -> same states; another seed -> different ones; test_reset (test_environments.py:192-214)
+    env.reset(seed=5)
+    assert np.array_equal(env.get(L.VS_STATE), f32(s))
+    env.reset(seed=6)
+    assert not np.array_equal(env.get(L.VS_STATE), f32(s))
+    env.close()
+
+
+@pytest.mark.parametrize("name", ENVS)
+def test_domain_randomization_on_device(vs, golden_dir, name):
+    """vs_sample_params with the reference's default randomizer table: moments, clipping, untouched params, and the
+    derived constants follow (checked by stepping against the oracle with the sampled params)"""
+    import json
+
+    L = vs._lib
+    tab = json.load(open(os.path.join(golden_dir, "randomizers.json")))[name]
+    specs = [(r["name"], "normal" if r["kind"] == "NormalDomainParam" else "uniform", r["mean"], r["spread"],
+              r["clip_lo"], r["clip_up"]) for r in tab["randomizer"]]
+    n = 50000
+    env = vs.VecSimEnv(name, n, **KW[name])
+    ref = cpu_ref.make_ref(name, **KW[name])
+    env.sample_params(specs, seed=11)
+    P = env.get(L.VS_PARAMS).astype(np.float64)
+    nominal = ref.nominal_params(1)[0]
+    touched = set()
+    for (pn, kind, mean, spread, lo, hi) in specs:
+        col = P[:, ref.param_names.index(pn)]
+        touched.add(pn)
+        assert (col >= np.float32(lo)).all() and (col <= np.float32(hi)).all()
+        if spread == 0:
+            continue
+        clipped = ((col <= np.float32(lo)) | (col >= np.float32(hi))).mean()
+        if clipped < 1e-3:
+            assert abs(col.mean() - mean) < 0.02 * spread + 1e-12
+            std = spread if kind == "normal" else spread / np.sqrt(3)
+            assert abs(col.std() - std) < 0.02 * std
+        if kind == "uniform":
+            assert col.min() >= mean - spread - 1e-6 * abs(mean) - 1e-9 and col.max() <= mean + spread + 1e-6 * abs(mean) + 1e-9
+    for j, pn in enumerate(ref.param_names):
+        if pn not in touched:
+            assert (P[:, j] == np.float32(nominal[j])).all()
+    # different lanes got different draws; same seed reproduces
+    assert np.unique(P[:, ref.param_names.index(specs[0][0])]).size > 0.99 * n
+    env2 = vs.VecSimEnv(name, n, **KW[name])
+    env2.sample_params(specs, seed=11)
+    assert np.array_equal(env2.get(L.VS_PARAMS), env.get(L.VS_PARAMS))
+    env2.close()
+    # constants follow the sampled params
+    rng = np.random.default_rng(1)
+    slo, shi, alo, ahi = ref.bounds(P)
+    state = f32(rng.uniform(-0.9, 0.9, slo.shape) * shi).astype(np.float64)
+    hidden = np.zeros((n, ref.H))
+    act = f32(rng.uniform(-1.2, 1.2, alo.shape) * ahi).astype(np.float64)
+    env.reset(init_state=f32(state))
+    if ref.H:
+        env.put(L.VS_HIDDEN, f32(hidden))
+    env.step(dev(act))
+    exp = ref.step(state, hidden, act, P, np.zeros(n, dtype=np.int64))
+    np.testing.assert_allclose(env.get(L.VS_STATE), exp["state"], rtol=RTOL_S, atol=ATOL_S)
+    np.testing.assert_allclose(env.get(L.VS_REW), exp["rew"], rtol=RTOL_R, atol=ATOL_R)
+    env.close()
+
+
+@pytest.mark.parametrize("name", ["omo", "bob", "qbb"])
+def test_random_rollout_kernel_with_auto_reset(vs, name):
+    """vs_step_random (k fused steps, on-device uniform policy, auto-reset) recorded and replayed
+    through the oracle lane by lane; completed-episode returns/lengths (ballot-compacted) must match the records"""
+    import json
+
+    L = vs._lib
+    n, T = 512, 700 if name == "omo" else 520
+    kw = dict(KW[name])
+    env = vs.VecSimEnv(name, n, **kw)
+    ref = cpu_ref.make_ref(name, **kw)
+    env.set_auto_reset(True, seed=3)
+    env.reset(seed=9)
+    env.step_random(T, seed=21, record=True)
+    tr = env.traj(T)
+    obs, act, rew, done = tr["obs"].astype(np.float64), tr["act"].astype(np.float64), tr["rew"], tr["done"].astype(bool)
+    params = ref.nominal_params(n)
+    _, _, alo, ahi = ref.bounds(params)
+    assert (act >= alo[None] - 1e-6).all() and (act <= ahi[None] + 1e-6).all()
+    assert abs(act.mean()) < 0.02 * ahi.max() and abs(act.std() - (ahi - alo).mean() / np.sqrt(12)) < 0.02 * ahi.max()
+    # replay: obs == state for these envs (qbb: the hidden plate angles are re-derived by carrying them along)
+    steps = np.zeros(n, dtype=np.int64)
+    hidden = ref.reset(params, obs[0], init_is_full_state=True)["hidden"]
+    ret = np.zeros(n)
+    ep_ret, ep_len = [], []
+    for t in range(T - 1):
+        out = ref.step(obs[t], hidden, act[t], params, steps)
+        np.testing.assert_allclose(rew[t], out["rew"], rtol=RTOL_R, atol=1e-6 if name == "omo" else ATOL_R)
+        margin = bound_margin(ref, out["state"], params).min(axis=1)
+        far = margin > 1e-5
+        assert np.array_equal(done[t][far], out["done"][far])
+        cont = ~done[t]
+        np.testing.assert_allclose(obs[t + 1][cont], out["state"][cont], rtol=RTOL_S, atol=ATOL_S)
+        ret += rew[t]
+        steps = steps + 1
+        for i in np.where(done[t])[0]:
+            ep_ret.append(ret[i])
+            ep_len.append(steps[i])
+        ret[done[t]] = 0
+        steps[done[t]] = 0
+        hidden = out["hidden"]
+        if done[t].any():  # fresh lanes: new init state from the init space, hidden re-initialised
+            fresh = ref.reset(params[done[t]], obs[t + 1][done[t]], init_is_full_state=True)
+            hidden[done[t]] = fresh["hidden"]
+    r, ln, ix = env.episodes()
+    # every episode that ended before the last step is in the device's episode buffer
+    assert len(r) >= len(ep_ret) > n // 2
+    got = sorted(zip(ln.tolist(), np.round(r, 3).tolist()))
+    exp = sorted(zip([int(x) for x in ep_len], np.round(np.asarray(ep_ret, dtype=np.float32), 3).tolist()))
+    assert len(got) - len(exp) == int(done[T - 1].sum())
+    matched = sum(1 for e in exp if any(abs(e[1] - g_[1]) <= 2e-3 * max(1, abs(e[1])) for g_ in got if g_[0] == e[0]))
+    assert matched == len(exp)
+    env.close()
+
+
+@pytest.mark.parametrize("name", ["qq-su", "qcp-su"])
+def test_rollout_kernel_equals_step_kernel(vs, name):
+    """k fused steps == k single-step launches fed with the recorded actions: bit-exact"""
+    L = vs._lib
+    n, T = 2048, 64
+    a = vs.VecSimEnv(name, n, **KW[name])
+    b = vs.VecSimEnv(name, n, **KW[name])
+    a.reset(seed=1)
+    b.reset(seed=1)
+    assert np.array_equal(a.get(L.VS_STATE), b.get(L.VS_STATE))
+    a.step_random(T, seed=4, record=True)
+    tr = a.traj(T)
+    for t in range(T):
+        b.step(dev(tr["act"][t]))
+        assert np.array_equal(b.get(L.VS_REW), tr["rew"][t])
+    for which in (L.VS_STATE, L.VS_OBS, L.VS_HIDDEN, L.VS_STEPCOUNT, L.VS_RETURNS, L.VS_DONE):
+        assert np.array_equal(a.get(which), b.get(which))
+    a.close()
+    b.close()
+
+
+def test_full_size_properties_qq_65536(vs):
+    """BASELINE metric config: 65 536 QQubeSwingUpSim envs.  Size-independent properties: determinism, lane independence
+    (env i in a batch of 65 536 == env i in a batch of 4 096), broadcast-constant kernel == per-env-constant kernel"""
+    L = vs._lib
+    n, m = 65536, 4096
+    big = vs.VecSimEnv("qq-su", n, **KW["qq-su"])
+    big2 = vs.VecSimEnv("qq-su", n, **KW["qq-su"])
+    small = vs.VecSimEnv("qq-su", m, **KW["qq-su"])
+    ref = cpu_ref.make_ref("qq-su", **KW["qq-su"])
+    big2.set_params(np.tile(vs.nominal_params("qq-su"), (n, 1)))  # per-env constants, same values
+    rng = np.random.default_rng(7)
+    lo, hi = ref.init_bounds(ref.nominal_params(n))
+    init = f32(rng.uniform(lo, hi))
+    for e, k in ((big, n), (big2, n), (small, m)):
+        e.reset(init_state=init[:k])
+    for t in range(50):
+        act = f32(rng.uniform(-5, 5, (n, 1)))
+        for e, k in ((big, n), (big2, n), (small, m)):
+            e.step(dev(act[:k]))
+    sb = big.get(L.VS_STATE)
+    assert np.array_equal(sb, big2.get(L.VS_STATE))
+    assert np.array_equal(sb[:m], small.get(L.VS_STATE))
+    assert np.array_equal(big.get(L.VS_RETURNS)[:m], small.get(L.VS_RETURNS))
+    assert np.isfinite(sb).all() and big.error_count() == 0
+    # spot-check 512 lanes of the big batch against the oracle for the last step
+    prev = big.get(L.VS_STATE)[:512].astype(np.float64)
+    act = f32(rng.uniform(-5, 5, (n, 1)))
+    big.step(dev(act))
+    exp = ref.step(prev, np.zeros((512, 0)), act[:512].astype(np.float64), ref.nominal_params(512), np.full(512, 50))
+    np.testing.assert_allclose(big.get(L.VS_STATE)[:512], exp["state"], rtol=RTOL_S, atol=ATOL_S)
+    for e in (big, big2, small):
+        e.close()
+
+
+def test_full_size_qcp_65536_live_dr(vs, golden_dir):
+    """BASELINE config 3: QCartPoleSwingUpSim + DomainRandWrapperLive over the first 7 default-randomizer params,
+    65 536 envs: params are redrawn at every (auto-)reset, stay inside their clip range, constants stay consistent"""
+    import json
+
+    L = vs._lib
+    tab = json.load(open(os.path.join(golden_dir, "randomizers.json")))["qcp-su"]["randomizer"][:7]
+    specs = [(r["name"], "normal" if r["kind"] == "NormalDomainParam" else "uniform", r["mean"], r["spread"],
+              r["clip_lo"], r["clip_up"]) for r in tab]
+    assert [s[0] for s in specs] == ["gravity_const", "cart_mass", "pole_mass", "rail_length", "pole_length",
+                                     "motor_efficiency", "gear_efficiency"]
+    n = 65536
+    env = vs.VecSimEnv("qcp-su", n, **KW["qcp-su"])
+    ref = cpu_ref.make_ref("qcp-su", **KW["qcp-su"])
+    env.set_randomizer(specs)
+    env.set_auto_reset(True, seed=2)
+    env.reset(seed=1)
+    p0 = env.get(L.VS_PARAMS)
+    assert np.unique(p0[:, 0]).size > 0.9 * n  # every env drew its own gravity at reset
+    env.step_random(400, seed=8)
+    r, ln, ix = env.episodes()
+    assert len(r) > 1000  # wild init + random actions: many carts hit the rail end
+    p1 = env.get(L.VS_PARAMS)
+    changed = (p1[:, 0] != p0[:, 0])
+    assert np.array_equal(np.unique(ix), np.where(changed)[0])  # exactly the envs that finished an episode were redrawn
+    for (pn, kind, mean, spread, lo, hi) in specs:
+        col = p1[:, ref.param_names.index(pn)]
+        assert (col >= np.float32(lo)).all() and (col <= np.float32(hi)).all()
+    # constants consistent with the (redrawn) params: one checked step on 2048 lanes
+    sel = slice(0, 2048)
+    P = p1[sel].astype(np.float64)
+    s = env.get(L.VS_STATE)[sel].astype(np.float64)
+    h = env.get(L.VS_HIDDEN)[sel].astype(np.float64)
+    c = env.get(L.VS_STEPCOUNT)[sel]
+    env.set_auto_reset(False)
+    env.set_randomizer([])
+    act = f32(np.random.default_rng(0).uniform(-6, 6, (n, 1)))
+    env.step(dev(act))
+    exp = ref.step(s, h, act[sel].astype(np.float64), P, c)
+    np.testing.assert_allclose(env.get(L.VS_STATE)[sel], exp["state"], rtol=RTOL_S, atol=ATOL_S)
+    np.testing.assert_allclose(env.get(L.VS_REW)[sel], exp["rew"], rtol=RTOL_R, atol=ATOL_R)
+    env.close()
+
+
+def test_edge_sizes(vs):
+    """N = 1 (reference-sized), ragged N (not a multiple of the 64-lane wave / 256-thread block)"""
+    L = vs._lib
+    ref = cpu_ref.make_ref("bob", **KW["bob"])
+    for n in (1, 63, 257, 1000):
+        env = vs.VecSimEnv("bob", n, **KW["bob"])
+        rng = np.random.default_rng(n)
+        state = f32(rng.uniform(-0.5, 0.5, (n, 4)))
+        act = f32(rng.uniform(-10, 10, (n, 1)))
+        env.reset(init_state=state)
+        env.step(dev(act))
+        exp = ref.step(state.astype(np.float64), np.zeros((n, 0)), act.astype(np.float64), ref.nominal_params(n),
+                       np.zeros(n, dtype=np.int64))
+        np.testing.assert_allclose(env.get(L.VS_STATE), exp["state"], rtol=RTOL_S, atol=ATOL_S)
+        env.step_random(3, seed=1)
+        assert env.get(L.VS_STEPCOUNT).tolist() == [4] * n
+        env.close()
