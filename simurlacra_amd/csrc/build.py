@@ -27,6 +27,9 @@ def build(force=False, verbose=False):
     if not force and not is_stale():
         return OUT
     cmd = [hipcc_path(), "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-Wall",
+           # contraction only inside one source expression: every kernel variant (step / fused rollout / broadcast or
+           # per-env constants) then rounds identically, which the bit-exactness tests rely on
+           "-ffp-contract=on",
            "-Wno-unused-function", "-o", OUT, SRC]
     if verbose:
         print(" ".join(cmd), flush=True)

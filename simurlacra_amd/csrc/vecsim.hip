@@ -236,7 +236,7 @@ __global__ __launch_bounds__(BLOCK) void k_step(Task T, Dev d, DrSpecs dr, const
 // Without auto-reset a finished lane freezes (rollout stops at done).
 template <class E, bool UNI, bool AR, bool REC>
 __global__ __launch_bounds__(BLOCK) void k_rollout(Task T, Dev d, DrSpecs dr, int k_steps, uint64_t seed,
-                                                   uint64_t epoch0) {
+                                                   uint64_t reset_seed, uint64_t epoch0) {
     int i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= d.ld) return;
     const size_t ld = d.ld;
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(BLOCK) void k_rollout(Task T, Dev d, DrSpecs dr, in
             append_episode(d, fin, i, ret, step);
             if (__ballot(fin) != 0ull) {
                 if (fin) {
-                    reset_lane_sampled<E>(T, d, dr, i, seed, epoch0 + (uint64_t)t, c, s, h);
+                    reset_lane_sampled<E>(T, d, dr, i, reset_seed, epoch0 + (uint64_t)t, c, s, h);
                     step = 0;
                     ret = 0.f;
                     yielded = false;
@@ -499,7 +499,7 @@ struct vs_env {
     hipStream_t own_stream = nullptr, stream = nullptr;
     Dev d{};
     int traj_cap = 0;
-    uint64_t epoch = 0;
+    uint64_t epoch = 1;  // 0 is reserved for the explicit-seed calls (vs_reset / vs_sample_params)
     std::string err;
     std::vector<void*> allocs;
     void* stage = nullptr;
@@ -622,7 +622,7 @@ template <class E>
 static void launch_rollout(vs_handle h, int k, uint64_t seed, uint64_t ep, bool rec) {
     dim3 g = grid_for(h->d.ld), b(BLOCK);
     bool uni = h->uniform && h->dr.n == 0;
-#define LR(U, AR, R) hipLaunchKernelGGL((k_rollout<E, U, AR, R>), g, b, 0, h->stream, h->task, h->d, h->dr, k, seed, ep)
+#define LR(U, AR, R) hipLaunchKernelGGL((k_rollout<E, U, AR, R>), g, b, 0, h->stream, h->task, h->d, h->dr, k, seed, h->ar_seed, ep)
     if (uni) {
         if (h->auto_reset) { if (rec) LR(true, true, true); else LR(true, true, false); }
         else { if (rec) LR(true, false, true); else LR(true, false, false); }
@@ -810,7 +810,7 @@ int vs_sample_params(vs_handle h, const vs_dp_spec* specs, int n_specs, uint64_t
     rc = stage_mask(h, mask, &m);
     if (rc) return rc;
     h->uniform = false;
-    uint64_t ep = h->epoch++;
+    uint64_t ep = 0;  // explicit seed: a pure function of (seed, env index)
     DISPATCH_ENV(h->type, hipLaunchKernelGGL(k_sample_params<E>, grid_for(h->d.ld), dim3(BLOCK), 0, h->stream,
                                               h->task, h->d, dr, seed, ep, m));
     HIPCHK(h, hipGetLastError());
@@ -840,7 +840,7 @@ int vs_reset(vs_handle h, const float* init_state, int64_t pitch, int full, cons
     }
     rc = stage_mask(h, mask, &m);
     if (rc) return rc;
-    uint64_t ep = h->epoch++;
+    uint64_t ep = 0;  // explicit seed: same (seed, env index) -> same init state / params (set_seed + reset semantics)
     DISPATCH_ENV(h->type, hipLaunchKernelGGL(k_reset<E>, grid_for(h->d.ld), dim3(BLOCK), 0, h->stream, h->task, h->d,
                                               h->dr, src, sp, full, m, seed, ep));
     HIPCHK(h, hipGetLastError());

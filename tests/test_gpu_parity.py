@@ -24,7 +24,7 @@ torch = pytest.importorskip("torch")
 ENVS = ["omo", "bob", "qq-su", "qcp-su", "qbb"]
 KW = {"omo": dict(dt=0.02, max_steps=300), "bob": dict(dt=0.01, max_steps=500), "qq-su": dict(dt=0.004, max_steps=4000),
       "qcp-su": dict(dt=0.002, max_steps=8000), "qbb": dict(dt=0.01, max_steps=500)}
-RTOL_S, ATOL_S = 1e-5, 2e-6
+RTOL_S, ATOL_S = 1e-5, 2e-6  # ATOL_S is multiplied by max(1, state bound) per dimension: see state_atol()
 RTOL_R, ATOL_R = 2e-4, 1e-12
 
 
@@ -49,6 +49,14 @@ def dev(x):
     return torch.from_numpy(np.ascontiguousarray(f32(x))).cuda()
 
 
+def assert_state_close(ref, got, exp, params):
+    """|got - exp| <= 1e-5 |exp| + 2e-6 * max(1, half-width of the state space in that dimension)"""
+    _, shi, _, _ = ref.bounds(np.asarray(params, dtype=np.float64))
+    tol = RTOL_S * np.abs(exp) + ATOL_S * np.maximum(1.0, np.abs(shi))
+    bad = np.abs(np.asarray(got, dtype=np.float64) - exp) > tol
+    assert not bad.any(), f"{bad.sum()} state elements out of tolerance, worst {np.abs(got - exp)[bad].max()}"
+
+
 def bound_margin(ref, nstate, params):
     slo, shi, _, _ = ref.bounds(params)
     scale = np.maximum(np.abs(shi), 1e-12)
@@ -57,8 +65,7 @@ def bound_margin(ref, nstate, params):
 
 def check_step(env, L, ref, params, state, hidden, act, curr_step, exp, yielded=None):
     """exp: dict with state/obs/rew/done(/hidden) from the reference or the oracle (fp64)"""
-    got_state = env.get(L.VS_STATE).astype(np.float64)
-    np.testing.assert_allclose(got_state, exp["state"], rtol=RTOL_S, atol=ATOL_S)
+    assert_state_close(ref, env.get(L.VS_STATE), exp["state"], params)
     np.testing.assert_allclose(env.get(L.VS_OBS), exp["obs"], rtol=RTOL_S, atol=ATOL_S)
     np.testing.assert_allclose(env.get(L.VS_REW), exp["rew"], rtol=RTOL_R, atol=ATOL_R)
     if ref.H:
@@ -110,7 +117,7 @@ def test_step_along_golden_trajectories(vs, golden_dir, name):
     g = load(golden_dir, "traj", name)
     ref = cpu_ref.make_ref(name, **KW[name])
     idx = [(i, t) for i in range(g["params"].shape[0]) for t in range(int(g["length"][i]))
-           if not (t > 0 and g["done"][i, t - 1])]  # steps after done carry the once-only final-reward flag
+           if not g["done"][i, :t].any()]  # steps after the first done carry the once-only final-reward flag
     ii, tt = np.array(idx).T
     env = vs.VecSimEnv(name, len(idx), **KW[name])
     setup_lanes(env, L, g["params"][ii], g["state"][ii, tt], g["hidden"][ii, tt], tt)
@@ -331,7 +338,7 @@ def test_domain_randomization_on_device(vs, golden_dir, name):
         env.put(L.VS_HIDDEN, f32(hidden))
     env.step(dev(act))
     exp = ref.step(state, hidden, act, P, np.zeros(n, dtype=np.int64))
-    np.testing.assert_allclose(env.get(L.VS_STATE), exp["state"], rtol=RTOL_S, atol=ATOL_S)
+    assert_state_close(ref, env.get(L.VS_STATE), exp["state"], P)
     np.testing.assert_allclose(env.get(L.VS_REW), exp["rew"], rtol=RTOL_R, atol=ATOL_R)
     env.close()
 
@@ -391,23 +398,41 @@ def test_random_rollout_kernel_with_auto_reset(vs, name):
     env.close()
 
 
-@pytest.mark.parametrize("name", ["qq-su", "qcp-su"])
-def test_rollout_kernel_equals_step_kernel(vs, name):
-    """k fused steps == k single-step launches fed with the recorded actions: bit-exact"""
+@pytest.mark.parametrize("auto_reset", [False, True])
+@pytest.mark.parametrize("name", ["qq-su", "qcp-su", "bob"])
+def test_rollout_kernel_equals_step_kernel(vs, name, auto_reset):
+    """k fused steps == k single-step launches fed with the recorded actions: bit-exact.  Without auto-reset a lane
+    that finished freezes in the fused kernel (rollout() stops at done) while vs_step keeps stepping, so lanes are
+    compared up to their first done; with auto-reset both kernels draw the same fresh episodes (same Philox counters)."""
     L = vs._lib
     n, T = 2048, 64
-    a = vs.VecSimEnv(name, n, **KW[name])
-    b = vs.VecSimEnv(name, n, **KW[name])
-    a.reset(seed=1)
-    b.reset(seed=1)
+    kw = dict(KW[name])
+    if name == "qq-su":
+        kw["max_steps"] = 40  # time-outs inside the window
+    a = vs.VecSimEnv(name, n, **kw)
+    b = vs.VecSimEnv(name, n, **kw)
+    for e in (a, b):
+        e.set_auto_reset(auto_reset, seed=17)
+        e.reset(seed=1)
     assert np.array_equal(a.get(L.VS_STATE), b.get(L.VS_STATE))
     a.step_random(T, seed=4, record=True)
     tr = a.traj(T)
+    alive = np.ones(n, dtype=bool)
     for t in range(T):
+        assert np.array_equal(b.get(L.VS_OBS)[alive], tr["obs"][t][alive])
         b.step(dev(tr["act"][t]))
-        assert np.array_equal(b.get(L.VS_REW), tr["rew"][t])
-    for which in (L.VS_STATE, L.VS_OBS, L.VS_HIDDEN, L.VS_STEPCOUNT, L.VS_RETURNS, L.VS_DONE):
-        assert np.array_equal(a.get(which), b.get(which))
+        assert np.array_equal(b.get(L.VS_REW)[alive], tr["rew"][t][alive])
+        assert np.array_equal(b.get(L.VS_DONE).astype(bool)[alive], tr["done"][t].astype(bool)[alive])
+        if not auto_reset:
+            alive &= ~tr["done"][t].astype(bool)
+    assert tr["done"].any() and (auto_reset or not alive.all())
+    for which in (L.VS_STATE, L.VS_OBS, L.VS_HIDDEN, L.VS_STEPCOUNT, L.VS_RETURNS):
+        assert np.array_equal(a.get(which)[alive], b.get(which)[alive])
+    if auto_reset:
+        ra, la, ia = a.episodes()
+        rb, lb, ib = b.episodes()
+        assert len(ra) == len(rb) > 0
+        assert sorted(zip(ia.tolist(), la.tolist(), ra.tolist())) == sorted(zip(ib.tolist(), lb.tolist(), rb.tolist()))
     a.close()
     b.close()
 
