@@ -149,7 +149,6 @@ def main():
     chunk = max(1, min(args.chunk, args.steps))
     n_launch = (args.steps + chunk - 1) // chunk
     steps = n_launch * chunk if args.mode == "fused" else args.steps
-    _, _, alo, ahi = (None, None, None, None)
     act_hi = {"omo": 30.0, "bob": 29.43, "qq-su": 4.5, "qcp-su": 6.0, "qbb": 3.0}[args.env]
 
     def run(k_steps):
@@ -177,9 +176,10 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    # gather completed-episode return statistics over RCCL (the only collective of this path)
-    r, ln, ix = env.episodes()
-    stats = torch.tensor([float(r.sum()), float(len(r)), float(ln.sum())], device=f"cuda:{local_rank}", dtype=torch.float64)
+    # gather completed-episode return statistics over RCCL (the only collective of this path): per-env accumulators
+    # reduced on the device, three doubles per rank on the wire
+    cnt_t, rs_t, ls_t = (env.tensor(w)[0, :n] for w in (L.VS_EPSTAT_COUNT, L.VS_EPSTAT_RETSUM, L.VS_EPSTAT_LENSUM))
+    stats = torch.stack([rs_t.double().sum(), cnt_t.double().sum(), ls_t.double().sum()])
     el_t = torch.tensor([el], device=f"cuda:{local_rank}", dtype=torch.float64)
     if dist:
         allstats = [torch.zeros_like(stats) for _ in range(world)]

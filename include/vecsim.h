@@ -55,7 +55,7 @@ enum vs_buffer {
     VS_RETURNS = 7,    /* f32 [ld]     undiscounted return of the running episode */
     VS_PARAMS = 8,     /* f32 [P][ld]  domain parameters, order = get_nominal_domain_param() */
     VS_CONSTS = 9,     /* f32 [K][ld]  derived constants (_calc_constants, bounds, c_max); layout in DESIGN.md */
-    VS_EP_RETURNS = 10,/* f32 [ep_cap] completed-episode returns, append order (ring) */
+    VS_EP_RETURNS = 10,/* f32 [ep_cap] episode log (vs_set_episode_log): completed-episode returns, append order (ring) */
     VS_EP_LENGTHS = 11,/* i32 [ep_cap] completed-episode lengths */
     VS_EP_ENVIDX = 12, /* i32 [ep_cap] env index of each completed episode */
     VS_EP_COUNT = 13,  /* u32 [1]      number of episodes appended since vs_clear_episodes */
@@ -64,7 +64,10 @@ enum vs_buffer {
     VS_TRAJ_REW = 16,  /* f32 [T][ld] */
     VS_TRAJ_DONE = 17, /* u8  [T][ld] */
     VS_FAILED = 18,    /* u8  [ld]     Task.has_failed(state) of the last step   P/tasks/base.py:159-167 */
-    VS_BUFFER_COUNT = 19
+    VS_EPSTAT_COUNT = 19,  /* u32 [ld]  completed episodes per env since vs_clear_episodes */
+    VS_EPSTAT_RETSUM = 20, /* f32 [ld]  sum of their undiscounted returns */
+    VS_EPSTAT_LENSUM = 21, /* i32 [ld]  sum of their lengths */
+    VS_BUFFER_COUNT = 22
 };
 
 /* vs_task_cfg.flags */
@@ -160,6 +163,11 @@ int vs_step(vs_handle h, const float* actions, int64_t env_stride, int64_t dim_s
  * record != 0 streams obs/act/rew/done of every step into the VS_TRAJ_* buffers (k_steps <= vs_traj_capacity). */
 int vs_step_random(vs_handle h, uint64_t seed, int k_steps, int record);
 int vs_set_traj_capacity(vs_handle h, int t_max);
+/* Episode bookkeeping.  Always on: per-env accumulators VS_EPSTAT_* (plain per-lane adds, no atomics) -- what the
+ * RCCL return gather reads.  Opt-in (vs_set_episode_log): every finished episode is also appended as (return, length,
+ * env index) to the VS_EP_* ring, compacted with a wavefront ballot and one atomic per wave; that atomic is a shared
+ * counter (about 90 appends/us chip-wide), so leave the log off on throughput runs with short episodes. */
+int vs_set_episode_log(vs_handle h, int on);
 int vs_clear_episodes(vs_handle h);
 
 /* ---- data access ---- */

@@ -31,6 +31,13 @@ struct Dev {
     float *state, *hidden, *obs, *rew, *ret, *consts, *params, *consts_uni;
     uint8_t *done, *failed, *err, *yielded;
     int* step;
+    uint32_t* ep_idx;   // per-env episode counter: the Philox counter of the NEXT reset of that env
+    // per-env statistics of completed episodes since vs_clear_episodes: plain per-lane accumulators, no atomics
+    uint32_t* es_count;
+    float* es_retsum;
+    int* es_lensum;
+    int log_episodes;   // opt-in: also append (return, length, env) to the global ring with ballot compaction
+    const DrSpecs* dr;  // device copy of the live randomizer (n == 0: none)
     float* ep_ret;
     int *ep_len, *ep_env;
     unsigned* ep_count;
@@ -69,10 +76,11 @@ struct StepOut {
     bool done, failed, err;
 };
 
-// SimPyEnv.step for one lane (P/environments/pysim/base.py:217-241); s, h, step, yielded are updated in place
+// SimPyEnv.step for one lane (P/environments/pysim/base.py:217-241); s, h, step, yielded are updated in place.
+// ob: observe() of the pre-step state if the caller holds it in registers (saves the trig it shares with the dynamics)
 template <class E>
 __device__ __forceinline__ StepOut step_one(const Task& T, const float* c, float* s, float* h, const float* a_raw,
-                                            int& step, bool& yielded) {
+                                            int& step, bool& yielded, const float* ob) {
     StepOut o;
     o.rew = step_reward<E>(T, c, s, a_raw);  // pre-step state, unclipped action (Q3)
     float alo[E::A], ahi[E::A], a[E::A];
@@ -84,7 +92,7 @@ __device__ __forceinline__ StepOut step_one(const Task& T, const float* c, float
         a[j] = fminf(fmaxf(a_raw[j], alo[j]), ahi[j]);  // limit_act -> BoxSpace.project_to (box.py:180-184)
         if (isnan(a_raw[j])) a[j] = a_raw[j];           // np.clip propagates NaN (fminf/fmaxf would drop it)
     }
-    E::dynamics(T, c, s, h, a);
+    E::dynamics(T, c, s, h, a, ob);
     step += 1;
     float slo[E::S], shi[E::S];
     E::state_bounds(c, slo, shi);
@@ -106,23 +114,18 @@ __device__ __forceinline__ StepOut step_one(const Task& T, const float* c, float
 }
 
 template <class E, bool UNI>
-__device__ __forceinline__ void load_consts(const Dev& d, int i, float* c, int count) {
-    if (UNI) {
+__device__ __forceinline__ void load_consts(const Dev& d, int i, float* c, int first, int last) {
 #pragma unroll
-        for (int k = 0; k < E::K; ++k)
-            if (k < count) c[k] = d.consts_uni[k];
-    } else {
-#pragma unroll
-        for (int k = 0; k < E::K; ++k)
-            if (k < count) c[k] = d.consts[(size_t)k * d.ld + i];
-    }
+    for (int k = 0; k < E::K; ++k)
+        if (k >= first && k < last) c[k] = UNI ? d.consts_uni[k] : d.consts[(size_t)k * d.ld + i];
 }
 
 // DomainRandomizer.randomize for one lane (domain_parameter.py:104-132): draw -> clamp; writes the raw params
 template <class E>
-__device__ __forceinline__ void draw_params(const DrSpecs& dr, Rng& g, float* p) {
-    for (int q = 0; q < dr.n; ++q) {
-        const vs_dp_spec& sp = dr.s[q];
+__device__ __forceinline__ void draw_params(const DrSpecs* dr, Rng& g, float* p) {
+    int n = dr->n;
+    for (int q = 0; q < n; ++q) {
+        const vs_dp_spec sp = dr->s[q];
         float v = sp.kind == VS_DP_NORMAL ? sp.mean + sp.spread * g.normal()
                                           : g.uniform(sp.mean - sp.spread, sp.mean + sp.spread);
         v = fminf(fmaxf(v, sp.clip_lo), sp.clip_up);
@@ -132,24 +135,30 @@ __device__ __forceinline__ void draw_params(const DrSpecs& dr, Rng& g, float* p)
     }
 }
 
-// SimPyEnv.reset for one lane with a sampled init state (P/environments/pysim/base.py:166-203), incl. the
-// DomainRandWrapperLive redraw (environment_wrappers/domain_randomization.py:141-148) when dr.n > 0
 template <class E>
-__device__ __forceinline__ void reset_lane_sampled(const Task& T, const Dev& d, const DrSpecs& dr, int i, uint64_t seed,
-                                                   uint64_t epoch, float* c, float* s, float* h) {
-    if (dr.n > 0) {
-        float p[E::P];
+__device__ __forceinline__ void redraw_lane_params(const Task& T, const Dev& d, const DrSpecs* dr, int i, uint64_t seed,
+                                                   uint64_t epi, float* c) {
+    float p[E::P];
 #pragma unroll
-        for (int k = 0; k < E::P; ++k) p[k] = d.params[(size_t)k * d.ld + i];
-        Rng gp(seed, (uint32_t)i, RNG_PARAM, epoch);
-        draw_params<E>(dr, gp, p);
-        E::calc_consts(T, p, c);
+    for (int k = 0; k < E::P; ++k) p[k] = d.params[(size_t)k * d.ld + i];
+    Rng gp(seed, (uint32_t)i, RNG_PARAM, epi);
+    draw_params<E>(dr, gp, p);
+    E::calc_consts(T, p, c);
 #pragma unroll
-        for (int k = 0; k < E::P; ++k) d.params[(size_t)k * d.ld + i] = p[k];
+    for (int k = 0; k < E::P; ++k) d.params[(size_t)k * d.ld + i] = p[k];
 #pragma unroll
-        for (int k = 0; k < E::K; ++k) d.consts[(size_t)k * d.ld + i] = c[k];
-    }
-    Rng g(seed, (uint32_t)i, RNG_INIT, epoch);
+    for (int k = 0; k < E::K; ++k) d.consts[(size_t)k * d.ld + i] = c[k];
+}
+
+// SimPyEnv.reset for one lane with a sampled init state (P/environments/pysim/base.py:166-203), incl. the
+// DomainRandWrapperLive redraw (environment_wrappers/domain_randomization.py:141-148) when a randomizer is set.
+// Every draw is a pure function of (seed, env index, episode index epi): independent of launch geometry, of how the
+// steps are chunked into launches and of hipGraph replay.
+template <class E>
+__device__ __forceinline__ void reset_lane_sampled(const Task& T, const Dev& d, bool with_dr, int i, uint64_t seed,
+                                                   uint64_t epi, float* c, float* s, float* h) {
+    if (with_dr && d.dr->n > 0) redraw_lane_params<E>(T, d, d.dr, i, seed, epi, c);
+    Rng g(seed, (uint32_t)i, RNG_INIT, epi);
     float init[E::I];
     E::sample_init(T, c, g, init);
     E::state_from_init(init, s);
@@ -161,9 +170,10 @@ __device__ __forceinline__ void append_episode(const Dev& d, bool fin, int i, fl
     unsigned long long m = __ballot(fin);
     if (m == 0ull) return;
     unsigned lane = __lane_id();
+    int leader = __ffsll((long long)m) - 1;
     unsigned base = 0;
-    if (lane == (unsigned)(__ffsll((long long)m) - 1)) base = atomicAdd(d.ep_count, (unsigned)__popcll(m));
-    base = __shfl(base, __ffsll((long long)m) - 1);
+    if ((int)lane == leader) base = atomicAdd(d.ep_count, (unsigned)__popcll(m));
+    base = __shfl(base, leader);
     if (fin) {
         unsigned slot = (base + (unsigned)__popcll(m & ((1ull << lane) - 1ull))) % d.ep_cap;
         d.ep_ret[slot] = ret;
@@ -172,16 +182,45 @@ __device__ __forceinline__ void append_episode(const Dev& d, bool fin, int i, fl
     }
 }
 
+// per-lane bookkeeping of finished episodes, kept in registers by the kernels
+struct EpStat {
+    uint32_t epi;    // Dev::ep_idx
+    uint32_t count;  // Dev::es_count
+    float retsum;    // Dev::es_retsum
+    int lensum;      // Dev::es_lensum
+};
+
+// auto-reset of the lanes of a wave that finished an episode (wave-uniform early out: most waves have none).
+// No memory traffic unless live domain randomisation rewrites the lane's params/constants or the episode log is on.
+template <class E, bool UNI>
+__device__ __forceinline__ void auto_reset(const Task& T, const Dev& d, bool fin, int i, uint64_t seed, float* c,
+                                           float* s, float* h, int& step, float& ret, bool& yielded, EpStat& es) {
+    if (__ballot(fin) == 0ull) return;
+    if (d.log_episodes) append_episode(d, fin, i, ret, step);
+    if (fin) {
+        es.count += 1u;
+        es.retsum += ret;
+        es.lensum += step;
+        load_consts<E, UNI>(d, i, c, E::KS, E::K);  // reset-only constants
+        reset_lane_sampled<E>(T, d, !UNI, i, seed, (uint64_t)es.epi, c, s, h);
+        es.epi += 1u;
+        step = 0;
+        ret = 0.f;
+        yielded = false;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------- step kernel
 // vs_step: one fused SimPyEnv.step per lane.  AR = auto-reset of finished lanes inside the same launch.
+// No host-side counter enters the kernel: replaying a captured hipGraph of vs_step launches is safe.
 template <class E, bool UNI, bool AR>
-__global__ __launch_bounds__(BLOCK) void k_step(Task T, Dev d, DrSpecs dr, const float* __restrict__ act,
-                                                long env_stride, long dim_stride, uint64_t seed, uint64_t epoch) {
+__global__ __launch_bounds__(BLOCK) void k_step(Task T, Dev d, const float* __restrict__ act, long env_stride,
+                                                long dim_stride, uint64_t seed) {
     int i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= d.ld) return;
     const size_t ld = d.ld;
     float c[E::K], s[E::S], h[E::H > 0 ? E::H : 1], a[E::A];
-    load_consts<E, UNI>(d, i, c, E::KS);
+    load_consts<E, UNI>(d, i, c, 0, E::KS);
 #pragma unroll
     for (int j = 0; j < E::S; ++j) s[j] = d.state[j * ld + i];
 #pragma unroll
@@ -192,7 +231,7 @@ __global__ __launch_bounds__(BLOCK) void k_step(Task T, Dev d, DrSpecs dr, const
     int step = d.step[i];
     bool yielded = E::HAS_FINAL ? d.yielded[i] != 0 : false;
 
-    StepOut o = step_one<E>(T, c, s, h, a, step, yielded);
+    StepOut o = step_one<E>(T, c, s, h, a, step, yielded, nullptr);
 
     float ret = d.ret[i] + o.rew;
     d.rew[i] = o.rew;
@@ -202,21 +241,19 @@ __global__ __launch_bounds__(BLOCK) void k_step(Task T, Dev d, DrSpecs dr, const
 
     if (AR) {
         bool fin = o.done && valid;
-        append_episode(d, fin, i, ret, step);
-        if (__ballot(fin) != 0ull) {  // wave-uniform skip: most waves have no finished lane
+        if (__ballot(fin) != 0ull) {  // single-step kernel: the per-env counters are touched by finishing lanes only
+            EpStat es{0u, 0u, 0.f, 0};
+            if (fin) es = EpStat{d.ep_idx[i], d.es_count[i], d.es_retsum[i], d.es_lensum[i]};
+            auto_reset<E, UNI>(T, d, fin, i, seed, c, s, h, step, ret, yielded, es);
             if (fin) {
-                if (UNI) load_consts<E, UNI>(d, i, c, E::K);
-                else {
-#pragma unroll
-                    for (int k = E::KS; k < E::K; ++k) c[k] = d.consts[(size_t)k * ld + i];
-                }
-                reset_lane_sampled<E>(T, d, dr, i, seed, epoch, c, s, h);
-                step = 0;
-                ret = 0.f;
-                yielded = false;
+                d.ep_idx[i] = es.epi;
+                d.es_count[i] = es.count;
+                d.es_retsum[i] = es.retsum;
+                d.es_lensum[i] = es.lensum;
             }
         }
     }
+
     float ob[E::O];
     E::observe(s, ob);
 #pragma unroll
@@ -234,15 +271,17 @@ __global__ __launch_bounds__(BLOCK) void k_step(Task T, Dev d, DrSpecs dr, const
 // vs_step_random: rollout() with DummyPolicy (rollout.py:185-239, dummy.py:77-84) -- k env steps per launch, state,
 // hidden state and constants stay in registers; only the per-step records stream to HBM when REC.
 // Without auto-reset a finished lane freezes (rollout stops at done).
+// Actions: Philox4x32-10 keyed by `seed`, counter (env, RNG_ACT, absolute step / SPB); one block feeds SPB = 4 / A
+// consecutive steps (the block boundary is wave-uniform because it depends on the launch-global step index only).
 template <class E, bool UNI, bool AR, bool REC>
-__global__ __launch_bounds__(BLOCK) void k_rollout(Task T, Dev d, DrSpecs dr, int k_steps, uint64_t seed,
-                                                   uint64_t reset_seed, uint64_t epoch0) {
+__global__ __launch_bounds__(BLOCK) void k_rollout(Task T, Dev d, int k_steps, uint64_t seed, uint64_t reset_seed,
+                                                   uint64_t epoch0) {
     int i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= d.ld) return;
     const size_t ld = d.ld;
     bool valid = i < d.n;
     float c[E::K], s[E::S], h[E::H > 0 ? E::H : 1], a[E::A], ob[E::O];
-    load_consts<E, UNI>(d, i, c, E::K);
+    load_consts<E, UNI>(d, i, c, 0, E::KS);
 #pragma unroll
     for (int j = 0; j < E::S; ++j) s[j] = d.state[j * ld + i];
 #pragma unroll
@@ -253,14 +292,27 @@ __global__ __launch_bounds__(BLOCK) void k_rollout(Task T, Dev d, DrSpecs dr, in
     bool frozen = !AR && d.done[i] != 0;
     float rew = d.rew[i];
     bool done = d.done[i] != 0, failed = d.failed[i] != 0;
+    EpStat es{d.ep_idx[i], d.es_count[i], d.es_retsum[i], d.es_lensum[i]};
     float alo[E::A], ahi[E::A];
-    E::observe(s, ob);
+    E::act_bounds(c, alo, ahi);
+    constexpr unsigned SPB = 4 / E::A;
+    uint4 blk = make_uint4(0, 0, 0, 0);
+    if (REC) E::observe(s, ob);
+    // gfx950 has ONE vmcnt for loads and stores, in issue order.  Drain the prologue loads here (0x0F70 = vmcnt(0) only) so
+    // that the waitcnt pass knows nothing is pending at the loop header: otherwise the conservative `vmcnt(N)` it places
+    // at the first in-loop use of a prologue load makes every later iteration wait for its own record stores to land.
+    __builtin_amdgcn_s_waitcnt(0x0F70);
 
     for (int t = 0; t < k_steps; ++t) {
-        E::act_bounds(c, alo, ahi);
-        Rng g(seed, (uint32_t)i, RNG_ACT, epoch0 + (uint64_t)t);
+        uint64_t ta = epoch0 + (uint64_t)t;
+        unsigned sub = (unsigned)(ta % SPB);
+        if (t == 0 || sub == 0) blk = Rng::philox(seed, (uint32_t)i, RNG_ACT, ta / SPB);
 #pragma unroll
-        for (int j = 0; j < E::A; ++j) a[j] = g.uniform(alo[j], ahi[j]);  // act_space.sample_uniform()
+        for (int j = 0; j < E::A; ++j) {
+            unsigned e = sub * E::A + j;  // wave-uniform element index
+            uint32_t bits = e == 0 ? blk.x : e == 1 ? blk.y : e == 2 ? blk.z : blk.w;
+            a[j] = alo[j] + (ahi[j] - alo[j]) * Rng::to_u01(bits);  // act_space.sample_uniform()
+        }
         if (REC) {
             size_t tb = (size_t)t;
 #pragma unroll
@@ -269,7 +321,7 @@ __global__ __launch_bounds__(BLOCK) void k_rollout(Task T, Dev d, DrSpecs dr, in
             for (int j = 0; j < E::A; ++j) d.traj_act[(tb * E::A + j) * ld + i] = a[j];
         }
         if (!frozen) {
-            StepOut o = step_one<E>(T, c, s, h, a, step, yielded);
+            StepOut o = step_one<E>(T, c, s, h, a, step, yielded, REC ? ob : nullptr);
             rew = o.rew;
             done = o.done;
             failed = o.failed;
@@ -284,21 +336,20 @@ __global__ __launch_bounds__(BLOCK) void k_rollout(Task T, Dev d, DrSpecs dr, in
         }
         bool fin = done && valid && !frozen;
         if (AR) {
-            append_episode(d, fin, i, ret, step);
-            if (__ballot(fin) != 0ull) {
-                if (fin) {
-                    reset_lane_sampled<E>(T, d, dr, i, reset_seed, epoch0 + (uint64_t)t, c, s, h);
-                    step = 0;
-                    ret = 0.f;
-                    yielded = false;
-                }
-            }
+            auto_reset<E, UNI>(T, d, fin, i, reset_seed, c, s, h, step, ret, yielded, es);
+            if (!UNI) E::act_bounds(c, alo, ahi);  // the action space may depend on redrawn params (omo, bob)
         } else {
-            append_episode(d, fin, i, ret, step);
+            if (fin) {  // rollout() ends here for this lane: book the episode once, then freeze
+                es.count += 1u;
+                es.retsum += ret;
+                es.lensum += step;
+            }
+            if (d.log_episodes) append_episode(d, fin, i, ret, step);
             frozen |= done;
         }
-        E::observe(s, ob);
+        if (REC) E::observe(s, ob);
     }
+    if (!REC) E::observe(s, ob);
 #pragma unroll
     for (int j = 0; j < E::S; ++j) d.state[j * ld + i] = s[j];
 #pragma unroll
@@ -311,6 +362,10 @@ __global__ __launch_bounds__(BLOCK) void k_rollout(Task T, Dev d, DrSpecs dr, in
     d.done[i] = done;
     d.failed[i] = failed;
     if (E::HAS_FINAL) d.yielded[i] = yielded;
+    d.ep_idx[i] = es.epi;
+    d.es_count[i] = es.count;
+    d.es_retsum[i] = es.retsum;
+    d.es_lensum[i] = es.lensum;
 }
 
 // -------------------------------------------------------------------------------------------- params / reset kernels
@@ -338,53 +393,35 @@ __global__ __launch_bounds__(BLOCK) void k_set_params(Task T, Dev d, const float
     }
 }
 
+// DomainRandomizer.randomize(N) + get_params on device; `specs` is a device copy of the spec list
 template <class E>
-__global__ __launch_bounds__(BLOCK) void k_sample_params(Task T, Dev d, DrSpecs dr, uint64_t seed, uint64_t epoch,
-                                                         const uint8_t* __restrict__ mask) {
+__global__ __launch_bounds__(BLOCK) void k_sample_params(Task T, Dev d, const DrSpecs* __restrict__ specs,
+                                                         uint64_t seed, const uint8_t* __restrict__ mask) {
     int i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= d.n) return;
     if (mask && mask[i] == 0) return;
-    float p[E::P], c[E::K];
-#pragma unroll
-    for (int k = 0; k < E::P; ++k) p[k] = d.params[(size_t)k * d.ld + i];
-    Rng g(seed, (uint32_t)i, RNG_PARAM, epoch);
-    draw_params<E>(dr, g, p);
-    E::calc_consts(T, p, c);
-#pragma unroll
-    for (int k = 0; k < E::P; ++k) d.params[(size_t)k * d.ld + i] = p[k];
-#pragma unroll
-    for (int k = 0; k < E::K; ++k) d.consts[(size_t)k * d.ld + i] = c[k];
+    float c[E::K];
+    redraw_lane_params<E>(T, d, specs, i, seed, 0ull, c);
 }
 
-// SimPyEnv.reset (P/environments/pysim/base.py:166-203) for masked lanes; init == nullptr samples the init space
+// SimPyEnv.reset (P/environments/pysim/base.py:166-203) for masked lanes; init == nullptr samples the init space.
+// The draws of an explicit reset use episode index 0: reset(seed) is a pure function of (seed, env index), like
+// pyrado.set_seed(seed) followed by env.reset() in the reference.
 template <class E>
-__global__ __launch_bounds__(BLOCK) void k_reset(Task T, Dev d, DrSpecs dr, const float* __restrict__ init, long pitch,
-                                                 int full_state, const uint8_t* __restrict__ mask, uint64_t seed,
-                                                 uint64_t epoch) {
+__global__ __launch_bounds__(BLOCK) void k_reset(Task T, Dev d, const float* __restrict__ init, long pitch,
+                                                 int full_state, const uint8_t* __restrict__ mask, uint64_t seed) {
     int i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= d.ld) return;
     bool valid = i < d.n;
     if (mask && (!valid || mask[i] == 0)) return;
     const size_t ld = d.ld;
     float c[E::K], s[E::S], h[E::H > 0 ? E::H : 1], ob[E::O];
-    load_consts<E, false>(d, i, c, E::K);
+    load_consts<E, false>(d, i, c, 0, E::K);
     if (init == nullptr || !valid) {
-        DrSpecs none;
-        none.n = 0;
-        reset_lane_sampled<E>(T, d, valid ? dr : none, i, seed, epoch, c, s, h);
+        reset_lane_sampled<E>(T, d, valid, i, seed, 0ull, c, s, h);
     } else {
-        if (dr.n > 0) {  // DomainRandWrapperLive.reset with an explicit init_state still redraws the params
-            float p[E::P];
-#pragma unroll
-            for (int k = 0; k < E::P; ++k) p[k] = d.params[(size_t)k * ld + i];
-            Rng gp(seed, (uint32_t)i, RNG_PARAM, epoch);
-            draw_params<E>(dr, gp, p);
-            E::calc_consts(T, p, c);
-#pragma unroll
-            for (int k = 0; k < E::P; ++k) d.params[(size_t)k * ld + i] = p[k];
-#pragma unroll
-            for (int k = 0; k < E::K; ++k) d.consts[(size_t)k * ld + i] = c[k];
-        }
+        // DomainRandWrapperLive.reset with an explicit init_state still redraws the params
+        if (d.dr->n > 0) redraw_lane_params<E>(T, d, d.dr, i, seed, 0ull, c);
         if (full_state) {
 #pragma unroll
             for (int j = 0; j < E::S; ++j) s[j] = init[(size_t)j * pitch + i];  // copied verbatim (base.py:184-188)
@@ -394,7 +431,7 @@ __global__ __launch_bounds__(BLOCK) void k_reset(Task T, Dev d, DrSpecs dr, cons
             for (int j = 0; j < E::I; ++j) in[j] = init[(size_t)j * pitch + i];
             E::state_from_init(in, s);
         }
-        float p[E::P > 0 ? E::P : 1];
+        float p[E::P];
 #pragma unroll
         for (int k = 0; k < E::P; ++k) p[k] = d.params[(size_t)k * ld + i];
         E::init_hidden(T, c, p, s, h, full_state != 0);
@@ -413,6 +450,7 @@ __global__ __launch_bounds__(BLOCK) void k_reset(Task T, Dev d, DrSpecs dr, cons
     d.failed[i] = 0;
     d.err[i] = 0;
     d.yielded[i] = 0;
+    d.ep_idx[i] = 1u;
 }
 
 // re-derive VS_OBS from VS_STATE after a host-side `state` assignment
@@ -492,14 +530,16 @@ struct vs_env {
     int type = 0;
     int device = 0;
     Task task{};
-    DrSpecs dr{};
+    DrSpecs dr{};                 // host copy of the live randomizer
+    DrSpecs* d_dr = nullptr;      // its device copy (Dev::dr)
+    DrSpecs* d_specs = nullptr;   // device scratch for vs_sample_params
     bool auto_reset = false;
     uint64_t ar_seed = 0;
     bool uniform = true;
     hipStream_t own_stream = nullptr, stream = nullptr;
     Dev d{};
     int traj_cap = 0;
-    uint64_t epoch = 1;  // 0 is reserved for the explicit-seed calls (vs_reset / vs_sample_params)
+    uint64_t epoch = 0;  // absolute step index of the action stream of vs_step_random
     std::string err;
     std::vector<void*> allocs;
     void* stage = nullptr;
@@ -606,23 +646,20 @@ static int check_specs(vs_handle h, const vs_dp_spec* specs, int n, DrSpecs* out
 }
 
 template <class E>
-static void launch_step(vs_handle h, const float* act, long es, long ds, uint64_t ep) {
+static void launch_step(vs_handle h, const float* act, long es, long ds) {
     dim3 g = grid_for(h->d.ld), b(BLOCK);
     bool uni = h->uniform && h->dr.n == 0;
-    if (h->auto_reset) {
-        if (uni) hipLaunchKernelGGL((k_step<E, true, true>), g, b, 0, h->stream, h->task, h->d, h->dr, act, es, ds, h->ar_seed, ep);
-        else hipLaunchKernelGGL((k_step<E, false, true>), g, b, 0, h->stream, h->task, h->d, h->dr, act, es, ds, h->ar_seed, ep);
-    } else {
-        if (uni) hipLaunchKernelGGL((k_step<E, true, false>), g, b, 0, h->stream, h->task, h->d, h->dr, act, es, ds, h->ar_seed, ep);
-        else hipLaunchKernelGGL((k_step<E, false, false>), g, b, 0, h->stream, h->task, h->d, h->dr, act, es, ds, h->ar_seed, ep);
-    }
+#define LS(U, AR) hipLaunchKernelGGL((k_step<E, U, AR>), g, b, 0, h->stream, h->task, h->d, act, es, ds, h->ar_seed)
+    if (h->auto_reset) { if (uni) LS(true, true); else LS(false, true); }
+    else { if (uni) LS(true, false); else LS(false, false); }
+#undef LS
 }
 
 template <class E>
 static void launch_rollout(vs_handle h, int k, uint64_t seed, uint64_t ep, bool rec) {
     dim3 g = grid_for(h->d.ld), b(BLOCK);
     bool uni = h->uniform && h->dr.n == 0;
-#define LR(U, AR, R) hipLaunchKernelGGL((k_rollout<E, U, AR, R>), g, b, 0, h->stream, h->task, h->d, h->dr, k, seed, h->ar_seed, ep)
+#define LR(U, AR, R) hipLaunchKernelGGL((k_rollout<E, U, AR, R>), g, b, 0, h->stream, h->task, h->d, k, seed, h->ar_seed, ep)
     if (uni) {
         if (h->auto_reset) { if (rec) LR(true, true, true); else LR(true, true, false); }
         else { if (rec) LR(true, false, true); else LR(true, false, false); }
@@ -719,6 +756,13 @@ int vs_create(int env_type, int64_t n_envs, double dt, int64_t max_steps, int de
     CK(dalloc(h, &d.err, ld));
     CK(dalloc(h, &d.yielded, ld));
     CK(dalloc(h, &d.step, ld));
+    CK(dalloc(h, &d.ep_idx, ld));
+    CK(dalloc(h, &d.es_count, ld));
+    CK(dalloc(h, &d.es_retsum, ld));
+    CK(dalloc(h, &d.es_lensum, ld));
+    CK(dalloc(h, &h->d_dr, (size_t)1));
+    CK(dalloc(h, &h->d_specs, (size_t)1));
+    d.dr = h->d_dr;
     d.ep_cap = (unsigned)(ld < (1u << 16) ? (1u << 16) : ld);
     CK(dalloc(h, &d.ep_ret, (size_t)d.ep_cap));
     CK(dalloc(h, &d.ep_len, (size_t)d.ep_cap));
@@ -809,10 +853,11 @@ int vs_sample_params(vs_handle h, const vs_dp_spec* specs, int n_specs, uint64_t
     const uint8_t* m;
     rc = stage_mask(h, mask, &m);
     if (rc) return rc;
+    HIPCHK(h, hipMemcpyAsync(h->d_specs, &dr, sizeof(DrSpecs), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));  // `dr` lives on this stack frame
     h->uniform = false;
-    uint64_t ep = 0;  // explicit seed: a pure function of (seed, env index)
     DISPATCH_ENV(h->type, hipLaunchKernelGGL(k_sample_params<E>, grid_for(h->d.ld), dim3(BLOCK), 0, h->stream,
-                                              h->task, h->d, dr, seed, ep, m));
+                                              h->task, h->d, (const DrSpecs*)h->d_specs, seed, m));
     HIPCHK(h, hipGetLastError());
     return VS_OK;
 }
@@ -822,7 +867,10 @@ int vs_set_randomizer(vs_handle h, const vs_dp_spec* specs, int n_specs) {
     DrSpecs dr;
     int rc = check_specs(h, specs, n_specs, &dr);
     if (rc) return rc;
+    HIPCHK(h, hipSetDevice(h->device));
     h->dr = dr;
+    HIPCHK(h, hipMemcpyAsync(h->d_dr, &h->dr, sizeof(DrSpecs), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
     if (n_specs > 0) h->uniform = false;
     return VS_OK;
 }
@@ -840,9 +888,8 @@ int vs_reset(vs_handle h, const float* init_state, int64_t pitch, int full, cons
     }
     rc = stage_mask(h, mask, &m);
     if (rc) return rc;
-    uint64_t ep = 0;  // explicit seed: same (seed, env index) -> same init state / params (set_seed + reset semantics)
     DISPATCH_ENV(h->type, hipLaunchKernelGGL(k_reset<E>, grid_for(h->d.ld), dim3(BLOCK), 0, h->stream, h->task, h->d,
-                                              h->dr, src, sp, full, m, seed, ep));
+                                              src, sp, full, m, seed));
     HIPCHK(h, hipGetLastError());
     return VS_OK;
 }
@@ -858,8 +905,7 @@ int vs_step(vs_handle h, const float* actions, int64_t env_stride, int64_t dim_s
     if (!h || !actions) return fail(h, VS_ERR_ARG, "vs_step: NULL argument");
     if (!is_device_ptr(actions)) return fail(h, VS_ERR_ARG, "vs_step: actions must be device memory");
     HIPCHK(h, hipSetDevice(h->device));
-    uint64_t ep = h->epoch++;
-    DISPATCH_ENV(h->type, launch_step<E>(h, actions, (long)env_stride, (long)dim_stride, ep));
+    DISPATCH_ENV(h->type, launch_step<E>(h, actions, (long)env_stride, (long)dim_stride));
     HIPCHK(h, hipGetLastError());
     return VS_OK;
 }
@@ -893,9 +939,18 @@ int vs_step_random(vs_handle h, uint64_t seed, int k_steps, int record) {
     return VS_OK;
 }
 
+int vs_set_episode_log(vs_handle h, int on) {
+    if (!h) return VS_ERR_ARG;
+    h->d.log_episodes = on != 0;
+    return VS_OK;
+}
+
 int vs_clear_episodes(vs_handle h) {
     if (!h) return VS_ERR_ARG;
     HIPCHK(h, hipMemsetAsync(h->d.ep_count, 0, sizeof(unsigned), h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d.es_count, 0, (size_t)h->d.ld * 4, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d.es_retsum, 0, (size_t)h->d.ld * 4, h->stream));
+    HIPCHK(h, hipMemsetAsync(h->d.es_lensum, 0, (size_t)h->d.ld * 4, h->stream));
     return VS_OK;
 }
 
@@ -923,6 +978,9 @@ static bool buf_info(vs_handle h, int which, void** p, size_t* bytes) {
         case VS_TRAJ_REW: *p = d.traj_rew; *bytes = (size_t)h->traj_cap * ld * 4; return true;
         case VS_TRAJ_DONE: *p = d.traj_done; *bytes = (size_t)h->traj_cap * ld; return true;
         case VS_FAILED: *p = d.failed; *bytes = ld; return true;
+        case VS_EPSTAT_COUNT: *p = d.es_count; *bytes = ld * 4; return true;
+        case VS_EPSTAT_RETSUM: *p = d.es_retsum; *bytes = ld * 4; return true;
+        case VS_EPSTAT_LENSUM: *p = d.es_lensum; *bytes = ld * 4; return true;
         default: return false;
     }
 }

@@ -63,6 +63,37 @@ __device__ __forceinline__ float fold_pi(float e) {
     return e;
 }
 
+// sin and cos of a BOUNDED angle (every angle on the hot path is a state inside / next to its box, |x| < ~1e3):
+// 3-term Cody-Waite reduction by pi/2 with FMAs (exact products), then the Cephes minimax polynomials on [-pi/4, pi/4].
+// ~25 VALU instructions for both values against ~150 for the general-range library sincosf (Payne-Hanek branch
+// included); max error measured against fp64 over |x| <= 100: < 1.2e-7 abs (tests/test_gpu_kernels.py).
+// NaN / inf inputs give NaN (the error flag relies on that).
+__device__ __forceinline__ void sincos_fast(float x, float* sn, float* cs) {
+    const float PIO2_HI = 1.57079637050628662109375f;       // (float)(pi/2)
+    const float PIO2_MID = -4.37113882867379127e-08f;       // (float)(pi/2 - HI)
+    const float PIO2_LO = -1.71512451008199912e-15f;        // (float)(pi/2 - HI - MID)
+    float q = rintf(x * 0.636619772367581343f);             // x * 2/pi
+    float r = fmaf(-q, PIO2_HI, x);
+    r = fmaf(-q, PIO2_MID, r);
+    r = fmaf(-q, PIO2_LO, r);
+    int n = (int)q;
+    float r2 = r * r;
+    float ps = fmaf(fmaf(fmaf(-1.9515295891e-4f, r2, 8.3321608736e-3f), r2, -1.6666654611e-1f), r2 * r, r);
+    float pc = fmaf(fmaf(fmaf(2.443315711809948e-5f, r2, -1.388731625493765e-3f), r2, 4.166664568298827e-2f), r2 * r2,
+                    fmaf(-0.5f, r2, 1.0f));
+    float s0 = (n & 1) ? pc : ps;
+    float c0 = (n & 1) ? ps : pc;
+    *sn = (n & 2) ? -s0 : s0;
+    *cs = ((n + 1) & 2) ? -c0 : c0;
+}
+
+// 1/x: v_rcp_f32 (1 ulp) + one Newton step; 3 instructions instead of the ~10 of an IEEE-rounded division.
+// Only for well-scaled positive denominators on the hot path (determinants, inertias); <= 1 ulp from the exact value.
+__device__ __forceinline__ float rcp_fast(float x) {
+    float r = __builtin_amdgcn_rcpf(x);
+    return fmaf(fmaf(-x, r, 1.0f), r, r);
+}
+
 __device__ __forceinline__ float sgnf(float x) { return (float)(x > 0.f) - (float)(x < 0.f); }  // np.sign
 
 // ------------------------------------------------------------------------------------------------- Philox4x32-10
@@ -76,9 +107,7 @@ struct Rng {
         ctr = make_uint4(env, purpose, (uint32_t)t, (uint32_t)(t >> 32));
         used = 4;
     }
-    __device__ __forceinline__ void block() {
-        uint4 c = ctr;
-        uint2 k = key;
+    __device__ __forceinline__ static uint4 rounds(uint4 c, uint2 k) {
 #pragma unroll
         for (int r = 0; r < 10; ++r) {
             uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
@@ -87,7 +116,16 @@ struct Rng {
             k.x += 0x9E3779B9u;
             k.y += 0xBB67AE85u;
         }
-        out = c;
+        return c;
+    }
+    // one block of four 32-bit words for (seed, env, purpose, t)
+    __device__ __forceinline__ static uint4 philox(uint64_t seed, uint32_t env, uint32_t purpose, uint64_t t) {
+        return rounds(make_uint4(env, purpose, (uint32_t)t, (uint32_t)(t >> 32)),
+                      make_uint2((uint32_t)seed, (uint32_t)(seed >> 32)));
+    }
+    __device__ __forceinline__ static float to_u01(uint32_t bits) { return (float)(bits >> 8) * (1.0f / 16777216.0f); }
+    __device__ __forceinline__ void block() {
+        out = rounds(ctr, key);
         ctr.y += 0x10000u;  // next block of the same (env, purpose, t) stream; purposes stay below 2^16
         used = 0;
     }
@@ -97,7 +135,7 @@ struct Rng {
         ++used;
         return v;
     }
-    __device__ __forceinline__ float u01() { return (float)(next() >> 8) * (1.0f / 16777216.0f); }  // [0, 1)
+    __device__ __forceinline__ float u01() { return to_u01(next()); }  // [0, 1)
     __device__ __forceinline__ float uniform(float lo, float hi) { return lo + (hi - lo) * u01(); }
     __device__ __forceinline__ float normal() {  // Box-Muller, one value per two uniforms
         float u1 = 1.0f - u01();                 // (0, 1]
@@ -127,7 +165,7 @@ struct Omo {
         hi[0] = 1.0f; hi[1] = 10.0f; lo[0] = -1.0f; lo[1] = -10.0f;
     }
     __device__ static void act_bounds(const float* c, float* lo, float* hi) { hi[0] = c[C_AMAX]; lo[0] = -c[C_AMAX]; }
-    __device__ static void dynamics(const Task& T, const float* c, float* s, float*, const float* a) {  // :105-114
+    __device__ static void dynamics(const Task& T, const float* c, float* s, float*, const float* a, const float*) {  // :105-114
         float sd0 = s[1];
         float sd1 = c[C_A10] * s[0] + c[C_A11] * s[1] + c[C_B1] * a[0];
         s[0] = s[0] + sd0 * T.dt;  // forward Euler
@@ -148,13 +186,13 @@ struct Bob {
     static constexpr int S = 4, A = 1, O = 4, H = 0, I = 4, P = 8, K = 9, KS = 9;
     static constexpr int REW = REW_SCALED_EXP, RADIAL = -1;
     static constexpr bool HAS_FINAL = false;
-    enum { C_MG, C_M, C_FRICT, C_OFF, C_ZETA_BALL, C_J_BEAM, C_XMAX, C_AMAX, C_CMAX };
+    enum { C_MG, C_M, C_FRICT, C_OFF, C_INV_ZETA_BALL, C_J_BEAM, C_XMAX, C_AMAX, C_CMAX };
     static constexpr int CMAX = C_CMAX;
     __device__ static void calc_consts(const Task& T, const float* p, float* c) {  // _calc_constants :89-98
         float g = p[0], m_ball = p[1], r_ball = p[2], m_beam = p[3], l_beam = p[4], d_beam = p[5];
         float J_ball = 2.0f / 5 * m_ball * r_ball * r_ball;
         c[C_J_BEAM] = 1.0f / 12 * m_beam * (l_beam * l_beam + d_beam * d_beam);
-        c[C_ZETA_BALL] = m_ball + J_ball / (r_ball * r_ball);
+        c[C_INV_ZETA_BALL] = 1.0f / (m_ball + J_ball / (r_ball * r_ball));  // 1 / zeta_ball
         c[C_MG] = m_ball * g;
         c[C_M] = m_ball;
         c[C_FRICT] = p[6];
@@ -173,13 +211,13 @@ struct Bob {
         for (int j = 0; j < 4; ++j) lo[j] = -hi[j];
     }
     __device__ static void act_bounds(const float* c, float* lo, float* hi) { hi[0] = c[C_AMAX]; lo[0] = -c[C_AMAX]; }
-    __device__ static void dynamics(const Task& T, const float* c, float* s, float*, const float* act) {  // :110-129
+    __device__ static void dynamics(const Task& T, const float* c, float* s, float*, const float* act, const float*) {  // :110-129
         float x = s[0], a = s[1] + c[C_OFF], x_dot = s[2], a_dot = s[3];
         float sa, ca;
-        sincosf(a, &sa, &ca);
+        sincos_fast(a, &sa, &ca);
         float zeta_beam = c[C_M] * x * x + c[C_J_BEAM];
-        float x_ddot = (-c[C_FRICT] * x_dot + c[C_M] * x * a_dot * a_dot - c[C_MG] * sa) / c[C_ZETA_BALL];
-        float a_ddot = (act[0] - 2.0f * c[C_M] * x * x_dot * a_dot - c[C_MG] * ca * x) / zeta_beam;
+        float x_ddot = (-c[C_FRICT] * x_dot + c[C_M] * x * a_dot * a_dot - c[C_MG] * sa) * c[C_INV_ZETA_BALL];
+        float a_ddot = (act[0] - 2.0f * c[C_M] * x * x_dot * a_dot - c[C_MG] * ca * x) * rcp_fast(zeta_beam);
         s[2] += x_ddot * T.dt;  // symplectic Euler: velocity first
         s[3] += a_ddot * T.dt;
         s[0] += s[2] * T.dt;
@@ -219,7 +257,7 @@ struct QQ {
         c[C_C2] = 0.5f * mp * Lp * Lr;
         c[C_C3] = Jp + c[C_C1];
         c[C_C4] = 0.5f * mp * Lp * g;
-        c[C_KM] = km; c[C_RM] = Rm; c[C_DR] = Dr; c[C_DP] = Dp;
+        c[C_KM] = km; c[C_RM] = 1.0f / Rm; c[C_DR] = Dr; c[C_DP] = Dp;
         c[C_TH_NEG] = p[9]; c[C_TH_POS] = p[10];
     }
     __device__ static void state_bounds(const float*, float* lo, float* hi) {  // _create_spaces :169
@@ -227,7 +265,8 @@ struct QQ {
         for (int j = 0; j < 4; ++j) lo[j] = -hi[j];
     }
     __device__ static void act_bounds(const float*, float* lo, float* hi) { hi[0] = 4.5f; lo[0] = -4.5f; }  // MAX_ACT_QQ
-    __device__ static void dynamics(const Task& T, const float* c, float* s, float*, const float* act) {
+    // ob: observation of the PRE-step state when the caller has it in registers (fused rollout), else nullptr
+    __device__ static void dynamics(const Task& T, const float* c, float* s, float*, const float* act, const float* ob) {
         // dead zone, _step_dynamics :130-131
         float u = act[0];
         if (c[C_TH_NEG] <= u && u <= c[C_TH_POS]) u = 0.f;
@@ -236,18 +275,19 @@ struct QQ {
         //   v' = v + dt a,  p' = p + dt v + dt^2/2 a        (closed form verified against the oracle: max abs diff 0)
         float thd = s[2], ald = s[3];
         float sin_al, cos_al;
-        sincosf(s[1], &sin_al, &cos_al);
+        if (ob) { sin_al = ob[2]; cos_al = ob[3]; }  // observe() already holds sin/cos(alpha) of this state
+        else sincos_fast(s[1], &sin_al, &cos_al);
         float sin_2al = 2.0f * sin_al * cos_al;
         float a = c[C_C0] + c[C_C1] * sin_al * sin_al;
         float b = c[C_C2] * cos_al;
         float cc = c[C_C3];
         float det = a * cc - b * b;
-        float trq = c[C_KM] * (u - c[C_KM] * thd) / c[C_RM];
+        float trq = c[C_KM] * (u - c[C_KM] * thd) * c[C_RM];  // C_RM holds 1 / Rm
         float c0 = c[C_C1] * sin_2al * thd * ald - c[C_C2] * sin_al * ald * ald;
         float c1 = -0.5f * c[C_C1] * sin_2al * thd * thd + c[C_C4] * sin_al;
         float x = trq - c[C_DR] * thd - c0;
         float y = -c[C_DP] * ald - c1;
-        float inv_det = 1.0f / det;
+        float inv_det = rcp_fast(det);
         float thdd = (cc * x - b * y) * inv_det;
         float aldd = (a * y - b * x) * inv_det;
         float dt = T.dt, hdt2 = 0.5f * dt * dt;
@@ -257,8 +297,8 @@ struct QQ {
         s[3] = ald + dt * aldd;
     }
     __device__ static void observe(const float* s, float* o) {  // :148-149
-        sincosf(s[0], &o[0], &o[1]);
-        sincosf(s[1], &o[2], &o[3]);
+        sincos_fast(s[0], &o[0], &o[1]);
+        sincos_fast(s[1], &o[2], &o[3]);
         o[4] = s[2];
         o[5] = s[3];
     }
@@ -312,10 +352,11 @@ struct Qcp {
     __device__ static void act_bounds(const float*, float* lo, float* hi) { hi[0] = 6.0f; lo[0] = -6.0f; }  // MAX_ACT_QCP
     // one evaluation of QCartPoleSim._dynamics (:166-230) on the augmented state y = [x, th, x_dot, th_dot], action u
     __device__ static void f_dyn(const Task& T, const float* c, const float* y, float u, float thdd_prev, float* k,
-                                 float& thdd_out) {
+                                 float& thdd_out, const float* ob) {
         float th = y[1], x_dot = y[2], th_dot = y[3];
         float sin_th, cos_th;
-        sincosf(th, &sin_th, &cos_th);
+        if (ob) { sin_th = ob[1]; cos_th = ob[2]; }
+        else sincos_fast(th, &sin_th, &cos_th);
         bool simple = (T.flags & 1) != 0;
         if (!simple && c[C_TH_NEG] <= u && u <= c[C_TH_POS]) u = 0.f;  // dead zone :188-192
         float f_act = c[C_KA] * (c[C_ETA_M] * u - c[C_KB] * x_dot);
@@ -329,7 +370,7 @@ struct Qcp {
         float r0 = f_tot - c[C_BEQ] * x_dot - c[C_MPL] * sin_th * th_dot * th_dot;
         float r1 = -c[C_BP] * th_dot - c[C_MPLG] * sin_th;
         // np.linalg.solve on the SPD 2x2 -> closed form
-        float inv_det = 1.0f / (c[C_M00] * c[C_M11] - M01 * M01);
+        float inv_det = rcp_fast(c[C_M00] * c[C_M11] - M01 * M01);
         float x_ddot = (c[C_M11] * r0 - M01 * r1) * inv_det;
         float th_ddot = (c[C_M00] * r1 - M01 * r0) * inv_det;
         k[0] = x_dot + x_ddot * T.dt;  // already Euler-advanced velocities as position derivative (Q6, :227-230)
@@ -338,24 +379,24 @@ struct Qcp {
         k[3] = th_ddot;
         thdd_out = th_ddot;
     }
-    __device__ static void dynamics(const Task& T, const float* c, float* s, float* h, const float* act) {
+    __device__ static void dynamics(const Task& T, const float* c, float* s, float* h, const float* act, const float* ob) {
         // rk4 (:591-655) over [x, th, x_dot, th_dot, u]; u has zero derivative; th_ddot chained through the stages.
         // The four stage vectors live in VGPRs (16 floats per lane): there is no cross-lane reuse to stage in LDS.
         float u = act[0], dt = T.dt, dt2 = dt / 2.0f;
         float k1[4], k2[4], k3[4], k4[4], y[4], a1, a2, a3, a4;
-        f_dyn(T, c, s, u, h[0], k1, a1);
+        f_dyn(T, c, s, u, h[0], k1, a1, ob);
         for (int j = 0; j < 4; ++j) y[j] = s[j] + dt2 * k1[j];
-        f_dyn(T, c, y, u, a1, k2, a2);
+        f_dyn(T, c, y, u, a1, k2, a2, nullptr);
         for (int j = 0; j < 4; ++j) y[j] = s[j] + dt2 * k2[j];
-        f_dyn(T, c, y, u, a2, k3, a3);
+        f_dyn(T, c, y, u, a2, k3, a3, nullptr);
         for (int j = 0; j < 4; ++j) y[j] = s[j] + dt * k3[j];
-        f_dyn(T, c, y, u, a3, k4, a4);
+        f_dyn(T, c, y, u, a3, k4, a4, nullptr);
         for (int j = 0; j < 4; ++j) s[j] = s[j] + dt / 6.0f * (k1[j] + 2.0f * k2[j] + 2.0f * k3[j] + k4[j]);
         h[0] = (a1 + a2 + a3 + a4) / 4.0f;  // mean of the stage th_ddots (:652)
     }
     __device__ static void observe(const float* s, float* o) {  // :107-108
         o[0] = s[0];
-        sincosf(s[1], &o[1], &o[2]);
+        sincos_fast(s[1], &o[1], &o[2]);
         o[3] = s[2];
         o[4] = s[3];
     }
@@ -417,7 +458,7 @@ struct Qbb {
         float r2 = r_ball * r_ball;
         c[C_AM] = eta_g * K_g * eta_m * k_m / R_m;
         c[C_BEQV] = eta_g * K_g * K_g * eta_m * k_m * k_m / R_m + B_eq;
-        c[C_JEQ] = eta_g * K_g * K_g * J_m + J_l;
+        c[C_JEQ] = 1.0f / (eta_g * K_g * K_g * J_m + J_l);  // 1 / J_eq
         c[C_CKIN] = c_kin;
         c[C_OFFX] = p[18]; c[C_OFFY] = p[19];
         c[C_TXP] = p[14]; c[C_TXN] = p[15]; c[C_TYP] = p[16]; c[C_TYN] = p[17];
@@ -425,7 +466,7 @@ struct Qbb {
         c[C_JBR] = J_ball * r_ball;               // plate influence :314
         c[C_MR2] = m_ball * r2;                   // centripetal :315
         c[C_CKMGR2] = c_kin * m_ball * g * r2;    // gravity :316
-        c[C_ZETA] = m_ball * r2 + J_ball;
+        c[C_ZETA] = 1.0f / (m_ball * r2 + J_ball);  // 1 / zeta
         c[C_XMAX] = l_plate / 2.0f;               // _create_spaces :97-107
         float smax[8] = {PI_4_F, PI_4_F, c[C_XMAX], c[C_XMAX], PI5_F, PI5_F, 0.5f, 0.5f};
         float mc = 0.f;
@@ -446,33 +487,34 @@ struct Qbb {
     __device__ static void act_bounds(const float*, float* lo, float* hi) {
         hi[0] = hi[1] = 3.0f; lo[0] = lo[1] = -3.0f;  // MAX_ACT_QBB
     }
-    __device__ static void dynamics(const Task& T, const float* c, float* s, float* h, const float* act) {  // :247-330
+    __device__ static void dynamics(const Task& T, const float* c, float* s, float* h, const float* act, const float*) {  // :247-330
         bool simple = (T.flags & 1) != 0;
         float a0 = act[0], a1 = act[1];
         if (!simple && c[C_TXN] <= a0 && a0 <= c[C_TXP]) a0 = 0.f;  // dead zones :261-264
         if (!simple && c[C_TYN] <= a1 && a1 <= c[C_TYP]) a1 = 0.f;
         float th_x = s[0] + c[C_OFFX], th_y = s[1] + c[C_OFFY];
         float x = s[2], y = s[3], th_x_dot = s[4], th_y_dot = s[5], x_dot = s[6], y_dot = s[7];
-        float th_x_ddot = (c[C_AM] * a0 - c[C_BEQV] * th_x_dot) / c[C_JEQ];
-        float th_y_ddot = (c[C_AM] * a1 - c[C_BEQV] * th_y_dot) / c[C_JEQ];
+        float th_x_ddot = (c[C_AM] * a0 - c[C_BEQV] * th_x_dot) * c[C_JEQ];  // C_JEQ holds 1 / J_eq
+        float th_y_ddot = (c[C_AM] * a1 - c[C_BEQV] * th_y_dot) * c[C_JEQ];
         float sx, cx, sy, cy, sa, ca, sb, cb;
-        sincosf(th_x, &sx, &cx);
-        sincosf(th_y, &sy, &cy);
-        sincosf(h[0], &sa, &ca);
-        sincosf(h[1], &sb, &cb);
+        sincos_fast(th_x, &sx, &cx);
+        sincos_fast(th_y, &sy, &cy);
+        sincos_fast(h[0], &sa, &ca);
+        sincos_fast(h[1], &sb, &cb);
         float ck = c[C_CKIN];
-        float a_dot = ck * th_x_dot * cx / ca;
-        float b_dot = ck * -th_y_dot * cy / cb;  // cos(-th_y) = cos(th_y)
+        float inv_ca = rcp_fast(ca), inv_cb = rcp_fast(cb);
+        float a_dot = ck * th_x_dot * cx * inv_ca;
+        float b_dot = ck * -th_y_dot * cy * inv_cb;  // cos(-th_y) = cos(th_y)
         float x_ddot, y_ddot;
         if (simple) {
-            x_ddot = c[C_CKMGR2] * sx / c[C_ZETA];
-            y_ddot = c[C_CKMGR2] * sy / c[C_ZETA];
+            x_ddot = c[C_CKMGR2] * sx * c[C_ZETA];  // C_ZETA holds 1 / zeta
+            y_ddot = c[C_CKMGR2] * sy * c[C_ZETA];
         } else {
-            float a_ddot = 1.0f / ca * (ck * (th_x_ddot * cx - th_x_dot * th_x_dot * sx) + a_dot * a_dot * sa);
+            float a_ddot = inv_ca * (ck * (th_x_ddot * cx - th_x_dot * th_x_dot * sx) + a_dot * a_dot * sa);
             // -(-th_y_dot)^2 * sin(-th_y) = + th_y_dot^2 * sin(th_y)
-            float b_ddot = 1.0f / cb * (ck * (-th_y_ddot * cy + th_y_dot * th_y_dot * sy) + b_dot * b_dot * sb);
-            x_ddot = (-c[C_BDR2] * x_dot - c[C_JBR] * a_ddot + c[C_MR2] * x * a_dot * a_dot + c[C_CKMGR2] * sx) / c[C_ZETA];
-            y_ddot = (-c[C_BDR2] * y_dot - c[C_JBR] * b_ddot + c[C_MR2] * y * b_dot * b_dot + c[C_CKMGR2] * sy) / c[C_ZETA];
+            float b_ddot = inv_cb * (ck * (-th_y_ddot * cy + th_y_dot * th_y_dot * sy) + b_dot * b_dot * sb);
+            x_ddot = (-c[C_BDR2] * x_dot - c[C_JBR] * a_ddot + c[C_MR2] * x * a_dot * a_dot + c[C_CKMGR2] * sx) * c[C_ZETA];
+            y_ddot = (-c[C_BDR2] * y_dot - c[C_JBR] * b_ddot + c[C_MR2] * y * b_dot * b_dot + c[C_CKMGR2] * sy) * c[C_ZETA];
         }
         float dt = T.dt;
         s[4] += th_x_ddot * dt; s[5] += th_y_ddot * dt; s[6] += x_ddot * dt; s[7] += y_ddot * dt;  // symplectic Euler

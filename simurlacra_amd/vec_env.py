@@ -18,6 +18,7 @@ _BUF_DTYPES = {
     L.VS_STATE: ("f4", "S"), L.VS_OBS: ("f4", "O"), L.VS_REW: ("f4", 1), L.VS_DONE: ("u1", 1),
     L.VS_HIDDEN: ("f4", "H"), L.VS_STEPCOUNT: ("i4", 1), L.VS_ERRFLAG: ("u1", 1), L.VS_RETURNS: ("f4", 1),
     L.VS_PARAMS: ("f4", "P"), L.VS_CONSTS: ("f4", "K"), L.VS_FAILED: ("u1", 1),
+    L.VS_EPSTAT_COUNT: ("u4", 1), L.VS_EPSTAT_RETSUM: ("f4", 1), L.VS_EPSTAT_LENSUM: ("i4", 1),
 }
 
 
@@ -303,7 +304,7 @@ class VecSimEnv:
         ptr = self._lib.vs_get(self._h, which)
         if not ptr or rows == 0:
             raise ValueErr(msg=f"buffer {which} is not available")
-        arr = _DevArray(ptr, (rows, self.ld), {"f4": "<f4", "u1": "|u1", "i4": "<i4"}[dt.str[1:]], self)
+        arr = _DevArray(ptr, (rows, self.ld), {"f4": "<f4", "u1": "|u1", "i4": "<i4", "u4": "<u4"}[dt.str[1:]], self)
         return torch.as_tensor(arr, device=f"cuda:{self.device}")
 
     def traj(self, k_steps):
@@ -321,8 +322,20 @@ class VecSimEnv:
             out[key] = t if rows > 1 or key in ("obs", "act") else t[..., 0]
         return out
 
+    def set_episode_log(self, on=True):
+        """Opt-in per-episode log (ballot-compacted ring). Off by default: see include/vecsim.h."""
+        self._check(self._lib.vs_set_episode_log(self._h, int(bool(on))), "vs_set_episode_log")
+
+    def episode_stats(self, clear=False):
+        """Per-env accumulators of completed episodes since the last clear: (count [N], return sum [N], length sum [N])"""
+        out = (self.get(L.VS_EPSTAT_COUNT), self.get(L.VS_EPSTAT_RETSUM), self.get(L.VS_EPSTAT_LENSUM))
+        if clear:
+            self._check(self._lib.vs_clear_episodes(self._h), "vs_clear_episodes")
+        return out
+
     def episodes(self, clear=True):
-        """Completed episodes since the last clear: (returns [M], lengths [M], env index [M])."""
+        """Episode log (needs set_episode_log(True)): completed episodes since the last clear as
+        (returns [M], lengths [M], env index [M])."""
         cnt = np.zeros(1, dtype=np.uint32)
         self._check(self._lib.vs_copy_to_host(self._h, L.VS_EP_COUNT, cnt.ctypes.data_as(C.c_void_p)), "vs_copy_to_host")
         cap = max(self.ld, 1 << 16)

@@ -355,6 +355,7 @@ def test_random_rollout_kernel_with_auto_reset(vs, name):
     env = vs.VecSimEnv(name, n, **kw)
     ref = cpu_ref.make_ref(name, **kw)
     env.set_auto_reset(True, seed=3)
+    env.set_episode_log(True)
     env.reset(seed=9)
     env.step_random(T, seed=21, record=True)
     tr = env.traj(T)
@@ -387,7 +388,12 @@ def test_random_rollout_kernel_with_auto_reset(vs, name):
         if done[t].any():  # fresh lanes: new init state from the init space, hidden re-initialised
             fresh = ref.reset(params[done[t]], obs[t + 1][done[t]], init_is_full_state=True)
             hidden[done[t]] = fresh["hidden"]
+    cnt, rsum, lsum = env.episode_stats()
     r, ln, ix = env.episodes()
+    # the per-env accumulators (no atomics) and the ballot-compacted log describe the same episodes
+    assert cnt.sum() == len(r) and lsum.sum() == ln.sum()
+    np.testing.assert_allclose(rsum.sum(dtype=np.float64), r.sum(dtype=np.float64), rtol=1e-5)
+    assert np.array_equal(np.bincount(ix, minlength=n), cnt)
     # every episode that ended before the last step is in the device's episode buffer
     assert len(r) >= len(ep_ret) > n // 2
     got = sorted(zip(ln.tolist(), np.round(r, 3).tolist()))
@@ -413,6 +419,7 @@ def test_rollout_kernel_equals_step_kernel(vs, name, auto_reset):
     b = vs.VecSimEnv(name, n, **kw)
     for e in (a, b):
         e.set_auto_reset(auto_reset, seed=17)
+        e.set_episode_log(True)
         e.reset(seed=1)
     assert np.array_equal(a.get(L.VS_STATE), b.get(L.VS_STATE))
     a.step_random(T, seed=4, record=True)
@@ -433,6 +440,8 @@ def test_rollout_kernel_equals_step_kernel(vs, name, auto_reset):
         rb, lb, ib = b.episodes()
         assert len(ra) == len(rb) > 0
         assert sorted(zip(ia.tolist(), la.tolist(), ra.tolist())) == sorted(zip(ib.tolist(), lb.tolist(), rb.tolist()))
+        for x, y in zip(a.episode_stats(), b.episode_stats()):
+            assert np.array_equal(x, y)
     a.close()
     b.close()
 
@@ -487,6 +496,7 @@ def test_full_size_qcp_65536_live_dr(vs, golden_dir):
     ref = cpu_ref.make_ref("qcp-su", **KW["qcp-su"])
     env.set_randomizer(specs)
     env.set_auto_reset(True, seed=2)
+    env.set_episode_log(True)
     env.reset(seed=1)
     p0 = env.get(L.VS_PARAMS)
     assert np.unique(p0[:, 0]).size > 0.9 * n  # every env drew its own gravity at reset
@@ -532,3 +542,23 @@ def test_edge_sizes(vs):
         env.step_random(3, seed=1)
         assert env.get(L.VS_STEPCOUNT).tolist() == [4] * n
         env.close()
+
+
+def test_fast_sincos_accuracy_through_observe(vs):
+    """the bounded-range sincos of the hot path (vecsim_envs.h: sincos_fast) against fp64 over |angle| <= 100 rad,
+    read back through QQubeSim.observe"""
+    L = vs._lib
+    n = 1 << 16
+    env = vs.VecSimEnv("qq-su", n, **KW["qq-su"])
+    rng = np.random.default_rng(0)
+    s = np.zeros((n, 4), dtype=np.float32)
+    s[:, 0] = rng.uniform(-100, 100, n)
+    s[:, 1] = np.concatenate([rng.uniform(-13, 13, n // 2), np.linspace(-4 * np.pi, 4 * np.pi, n // 2)])
+    s[:16, 0] = np.arange(16) * np.float32(np.pi / 4)  # multiples of pi/4: quadrant boundaries
+    env.reset(init_state=s)
+    o = env.get(L.VS_OBS).astype(np.float64)
+    s64 = s.astype(np.float64)
+    exp = np.stack([np.sin(s64[:, 0]), np.cos(s64[:, 0]), np.sin(s64[:, 1]), np.cos(s64[:, 1])], axis=1)
+    err = np.abs(o[:, :4] - exp).max()
+    assert err < 2.0e-7, err
+    env.close()
