@@ -30,6 +30,8 @@ def build(force=False, verbose=False):
            # contraction only inside one source expression: every kernel variant (step / fused rollout / broadcast or
            # per-env constants) then rounds identically, which the bit-exactness tests rely on
            "-ffp-contract=on",
+           # packed fp32 VALU ops (v_pk_fma_f32 ...) issue slower than the two scalar ops they replace on gfx950
+           "-fno-slp-vectorize",
            "-Wno-unused-function", "-o", OUT, SRC]
     if verbose:
         print(" ".join(cmd), flush=True)

@@ -9,6 +9,7 @@
 #include <climits>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -37,7 +38,8 @@ struct Dev {
     float* es_retsum;
     int* es_lensum;
     int log_episodes;   // opt-in: also append (return, length, env) to the global ring with ballot compaction
-    const DrSpecs* dr;  // device copy of the live randomizer (n == 0: none)
+    const DrSpecs* dr;  // device copy of the live randomizer
+    int dr_n;           // its number of specs, by value: the reset path must not wait on a load to learn there is none
     float* ep_ret;
     int *ep_len, *ep_env;
     unsigned* ep_count;
@@ -100,7 +102,9 @@ __device__ __forceinline__ StepOut step_one(const Task& T, const float* c, float
 #pragma unroll
     for (int j = 0; j < E::S; ++j) {
         o.err |= isnan(s[j]);
-        o.failed |= (s[j] < slo[j]) | (s[j] > shi[j]);  // not state_space.contains(s') (Q9, Q10)
+        // not state_space.contains(s') (Q9, Q10): s < lo or s > hi; every state box of the five envs is symmetric
+        // (lo == -hi), so this is |s| > hi -- one compare with the abs modifier, NaN compares false as in NumPy
+        o.failed |= E::SYMMETRIC_BOX ? (fabsf(s[j]) > shi[j]) : ((s[j] < slo[j]) | (s[j] > shi[j]));
     }
     o.done = o.failed | (step >= T.max_steps);
     if (E::HAS_FINAL) {
@@ -157,7 +161,7 @@ __device__ __forceinline__ void redraw_lane_params(const Task& T, const Dev& d, 
 template <class E>
 __device__ __forceinline__ void reset_lane_sampled(const Task& T, const Dev& d, bool with_dr, int i, uint64_t seed,
                                                    uint64_t epi, float* c, float* s, float* h) {
-    if (with_dr && d.dr->n > 0) redraw_lane_params<E>(T, d, d.dr, i, seed, epi, c);
+    if (with_dr && d.dr_n > 0) redraw_lane_params<E>(T, d, d.dr, i, seed, epi, c);
     Rng g(seed, (uint32_t)i, RNG_INIT, epi);
     float init[E::I];
     E::sample_init(T, c, g, init);
@@ -421,7 +425,7 @@ __global__ __launch_bounds__(BLOCK) void k_reset(Task T, Dev d, const float* __r
         reset_lane_sampled<E>(T, d, valid, i, seed, 0ull, c, s, h);
     } else {
         // DomainRandWrapperLive.reset with an explicit init_state still redraws the params
-        if (d.dr->n > 0) redraw_lane_params<E>(T, d, d.dr, i, seed, 0ull, c);
+        if (d.dr_n > 0) redraw_lane_params<E>(T, d, d.dr, i, seed, 0ull, c);
         if (full_state) {
 #pragma unroll
             for (int j = 0; j < E::S; ++j) s[j] = init[(size_t)j * pitch + i];  // copied verbatim (base.py:184-188)
@@ -869,6 +873,7 @@ int vs_set_randomizer(vs_handle h, const vs_dp_spec* specs, int n_specs) {
     if (rc) return rc;
     HIPCHK(h, hipSetDevice(h->device));
     h->dr = dr;
+    h->d.dr_n = dr.n;
     HIPCHK(h, hipMemcpyAsync(h->d_dr, &h->dr, sizeof(DrSpecs), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (n_specs > 0) h->uniform = false;

@@ -46,14 +46,12 @@ __device__ __forceinline__ float fmod_2pi(float e) {
     float r = fmaf(-q, TWO_PI_HI, e);
     r = fmaf(-q, TWO_PI_LO, r);
     // q may be off by one when e/2pi rounds across an integer: bring r back to (-2pi, 2pi) with the sign of e
-    if (e >= 0.f) {
-        if (r < 0.f) r += TWO_PI_F;
-        if (r >= TWO_PI_F) r -= TWO_PI_F;
-    } else {
-        if (r > 0.f) r -= TWO_PI_F;
-        if (r <= -TWO_PI_F) r += TWO_PI_F;
-    }
-    return r;
+    // (branch-free: work on |r'| = r * sign(e), which must end up in [0, 2pi))
+    float sg = copysignf(1.0f, e);
+    float m = r * sg;
+    m = m < 0.f ? m + TWO_PI_F : m;
+    m = m >= TWO_PI_F ? m - TWO_PI_F : m;
+    return m * sg;
 }
 
 // the two sequential +-pi folds of RadiallySymmDesStateTask.step_rew (P/tasks/desired_state.py:152-153, Q4)
@@ -110,8 +108,9 @@ struct Rng {
     __device__ __forceinline__ static uint4 rounds(uint4 c, uint2 k) {
 #pragma unroll
         for (int r = 0; r < 10; ++r) {
-            uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
-            uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+            // one 32x32->64 multiply per word pair (v_mad_u64_u32): integer multiplies are quarter-rate on CDNA4
+            uint64_t p0 = (uint64_t)0xD2511F53u * c.x, p1 = (uint64_t)0xCD9E8D57u * c.z;
+            uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0, hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
             c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
             k.x += 0x9E3779B9u;
             k.y += 0xBB67AE85u;
@@ -150,6 +149,7 @@ enum RngPurpose { RNG_ACT = 1, RNG_INIT = 2, RNG_PARAM = 3 };
 struct Omo {
     static constexpr int S = 2, A = 1, O = 2, H = 0, I = 2, P = 3, K = 4, KS = 4;
     static constexpr int REW = REW_QUADR, RADIAL = -1, CMAX = -1;
+    static constexpr bool SYMMETRIC_BOX = true;
     static constexpr bool HAS_FINAL = true;  // FinalRewTask(factor 1e3, always_negative), :75-79
     enum { C_A10, C_A11, C_B1, C_AMAX };
     __device__ static void calc_consts(const Task&, const float* p, float* c) {  // _calc_constants :88-103
@@ -186,6 +186,7 @@ struct Bob {
     static constexpr int S = 4, A = 1, O = 4, H = 0, I = 4, P = 8, K = 9, KS = 9;
     static constexpr int REW = REW_SCALED_EXP, RADIAL = -1;
     static constexpr bool HAS_FINAL = false;
+    static constexpr bool SYMMETRIC_BOX = true;
     enum { C_MG, C_M, C_FRICT, C_OFF, C_INV_ZETA_BALL, C_J_BEAM, C_XMAX, C_AMAX, C_CMAX };
     static constexpr int CMAX = C_CMAX;
     __device__ static void calc_consts(const Task& T, const float* p, float* c) {  // _calc_constants :89-98
@@ -247,6 +248,7 @@ struct QQ {
     static constexpr int S = 4, A = 1, O = 6, H = 0, I = 4, P = 11, K = 11, KS = 11;
     static constexpr int REW = REW_EXP, RADIAL = 1, CMAX = -1;
     static constexpr bool HAS_FINAL = false;
+    static constexpr bool SYMMETRIC_BOX = true;
     enum { C_C0, C_C1, C_C2, C_C3, C_C4, C_KM, C_RM, C_DR, C_DP, C_TH_NEG, C_TH_POS };
     __device__ static void calc_consts(const Task&, const float* p, float* c) {  // _calc_constants :70-87
         float g = p[0], Rm = p[1], km = p[2], mr = p[3], Lr = p[4], Dr = p[5], mp = p[6], Lp = p[7], Dp = p[8];
@@ -321,6 +323,7 @@ struct Qcp {
     static constexpr int S = 4, A = 1, O = 5, H = 1, I = 4, P = 17, K = 16, KS = 16;
     static constexpr int REW = REW_EXP, RADIAL = 1, CMAX = -1;
     static constexpr bool HAS_FINAL = false;
+    static constexpr bool SYMMETRIC_BOX = true;
     enum { C_KA, C_ETA_M, C_KB, C_MTG, C_MPL2, C_MU, C_M00, C_MPL, C_M11, C_BEQ, C_BP, C_MPLG, C_TH_NEG, C_TH_POS,
            C_XMAX, C_XDMAX };
     __device__ static void calc_consts(const Task&, const float* p, float* c) {  // _calc_constants :145-155 + _dynamics
@@ -447,6 +450,7 @@ struct Qbb {
     static constexpr int S = 8, A = 2, O = 8, H = 2, I = 4, P = 20, K = 19, KS = 17;
     static constexpr int REW = REW_SCALED_EXP, RADIAL = -1;
     static constexpr bool HAS_FINAL = false;
+    static constexpr bool SYMMETRIC_BOX = true;
     enum { C_AM, C_BEQV, C_JEQ, C_CKIN, C_OFFX, C_OFFY, C_TXP, C_TXN, C_TYP, C_TYN, C_BDR2, C_JBR, C_MR2, C_CKMGR2,
            C_ZETA, C_XMAX, C_CMAX, C_IK_X0, C_IK_Y0 };
     static constexpr int CMAX = C_CMAX;
