@@ -144,8 +144,12 @@ def main():
     env = vs.VecSimEnv(args.env, n, device=local_rank, **kw)
     if args.per_env_params:
         env.set_params(np.tile(vs.nominal_params(args.env), (n, 1)))
-    env.set_auto_reset(True, seed=args.seed * 1000 + rank)
-    env.reset(seed=args.seed * 7919 + rank)  # per-rank Philox stream
+    from simurlacra_amd.dist import gather_episode_stats, shard
+
+    first, _ = shard(n * world, rank, world)
+    env.set_index_offset(first)  # global env index: lane streams do not depend on the number of GPUs
+    env.set_auto_reset(True, seed=args.seed * 1000 + 1)
+    env.reset(seed=args.seed * 7919 + 2)
     chunk = max(1, min(args.chunk, args.steps))
     n_launch = (args.steps + chunk - 1) // chunk
     steps = n_launch * chunk if args.mode == "fused" else args.steps
@@ -154,7 +158,7 @@ def main():
     def run(k_steps):
         if args.mode == "fused":
             for _ in range((k_steps + chunk - 1) // chunk):
-                env.step_random(chunk, seed=args.seed + rank, record=bool(args.record))
+                env.step_random(chunk, seed=args.seed + 3, record=bool(args.record))
         else:
             for _ in range(k_steps):
                 act = (torch.rand(n, d["A"], device=f"cuda:{local_rank}") * 2 - 1) * act_hi
@@ -179,13 +183,10 @@ def main():
     # gather completed-episode return statistics over RCCL (the only collective of this path): per-env accumulators
     # reduced on the device, three doubles per rank on the wire
     cnt_t, rs_t, ls_t = (env.tensor(w)[0, :n] for w in (L.VS_EPSTAT_COUNT, L.VS_EPSTAT_RETSUM, L.VS_EPSTAT_LENSUM))
-    stats = torch.stack([rs_t.double().sum(), cnt_t.double().sum(), ls_t.double().sum()])
+    ep = gather_episode_stats(cnt_t, rs_t, ls_t)
     el_t = torch.tensor([el], device=f"cuda:{local_rank}", dtype=torch.float64)
     if dist:
-        allstats = [torch.zeros_like(stats) for _ in range(world)]
-        dist.all_gather(allstats, stats)
         dist.all_reduce(el_t, op=dist.ReduceOp.MAX)
-        stats = torch.stack(allstats).sum(dim=0)
     el = float(el_t.item())
     errs = env.error_count()
 
@@ -220,8 +221,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": kname,
                          "kernel_ms": ms, "alg_bytes_per_env_step": b_per, "env_steps_per_launch": units},
-            "episodes": {"completed": int(stats[1].item()), "mean_return": float(stats[0].item() / max(stats[1].item(), 1)),
-                         "mean_length": float(stats[2].item() / max(stats[1].item(), 1))},
+            "episodes": {"completed": ep["episodes"], "mean_return": ep["mean_return"], "mean_length": ep["mean_length"]},
             "nan_flags": errs,
         }
         if not args.no_cpu_baseline and world == 1:

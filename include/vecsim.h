@@ -149,6 +149,10 @@ int vs_set_randomizer(vs_handle h, const vs_dp_spec* specs, int n_specs);
  * mask as above.  seed keys the Philox stream used for sampling (and for live domain randomisation). */
 int vs_reset(vs_handle h, const float* init_state, int64_t pitch, int init_is_full_state, const uint8_t* mask,
              uint64_t seed);
+/* Global index of lane 0 (default 0).  Every random stream of lane i is keyed by (first_global_index + i): a set of
+ * envs gives the same trajectories whether it lives in one handle, is cut into batches, or is sharded over GPUs
+ * (rank r of a node passes r * n_envs). */
+int vs_set_index_offset(vs_handle h, uint32_t first_global_index);
 /* when on, a lane whose episode ended is reset inside the same step kernel (fresh init state, redrawn params when a
  * randomizer is set); VS_OBS then holds the first observation of the new episode, VS_REW/VS_DONE the finished step */
 int vs_set_auto_reset(vs_handle h, int on, uint64_t seed);
@@ -162,6 +166,9 @@ int vs_step(vs_handle h, const float* actions, int64_t env_stride, int64_t dim_s
  * k_steps env steps in ONE launch with on-device uniform actions in act_space, state kept in registers.
  * record != 0 streams obs/act/rew/done of every step into the VS_TRAJ_* buffers (k_steps <= vs_traj_capacity). */
 int vs_step_random(vs_handle h, uint64_t seed, int k_steps, int record);
+/* The action stream of vs_step_random is Philox(seed; global env index, absolute step index); the handle counts the
+ * steps it has taken.  vs_seek_random repositions that counter (0 = start of a fresh batch of rollouts). */
+int vs_seek_random(vs_handle h, uint64_t step_index);
 int vs_set_traj_capacity(vs_handle h, int t_max);
 /* Episode bookkeeping.  Always on: per-env accumulators VS_EPSTAT_* (plain per-lane adds, no atomics) -- what the
  * RCCL return gather reads.  Opt-in (vs_set_episode_log): every finished episode is also appended as (return, length,

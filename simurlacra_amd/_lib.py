@@ -43,9 +43,11 @@ _SIGNATURES = {
     "vs_sample_params": (C.c_int, [_P, C.POINTER(DpSpec), C.c_int, C.c_uint64, _P]),
     "vs_set_randomizer": (C.c_int, [_P, C.POINTER(DpSpec), C.c_int]),
     "vs_reset": (C.c_int, [_P, _P, C.c_int64, C.c_int, _P, C.c_uint64]),
+    "vs_set_index_offset": (C.c_int, [_P, C.c_uint32]),
     "vs_set_auto_reset": (C.c_int, [_P, C.c_int, C.c_uint64]),
     "vs_step": (C.c_int, [_P, _P, C.c_int64, C.c_int64]),
     "vs_step_random": (C.c_int, [_P, C.c_uint64, C.c_int, C.c_int]),
+    "vs_seek_random": (C.c_int, [_P, C.c_uint64]),
     "vs_set_traj_capacity": (C.c_int, [_P, C.c_int]),
     "vs_set_episode_log": (C.c_int, [_P, C.c_int]),
     "vs_clear_episodes": (C.c_int, [_P]),

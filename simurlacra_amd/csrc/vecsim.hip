@@ -39,6 +39,8 @@ struct Dev {
     int* es_lensum;
     int log_episodes;   // opt-in: also append (return, length, env) to the global ring with ballot compaction
     const DrSpecs* dr;  // device copy of the live randomizer
+    uint32_t idx0;      // global index of lane 0: every Philox stream is keyed by (idx0 + lane), so results do not depend
+                        // on how a set of envs is split into handles, batches or GPUs
     int dr_n;           // its number of specs, by value: the reset path must not wait on a load to learn there is none
     float* ep_ret;
     int *ep_len, *ep_env;
@@ -145,7 +147,7 @@ __device__ __forceinline__ void redraw_lane_params(const Task& T, const Dev& d, 
     float p[E::P];
 #pragma unroll
     for (int k = 0; k < E::P; ++k) p[k] = d.params[(size_t)k * d.ld + i];
-    Rng gp(seed, (uint32_t)i, RNG_PARAM, epi);
+    Rng gp(seed, d.idx0 + (uint32_t)i, RNG_PARAM, epi);
     draw_params<E>(dr, gp, p);
     E::calc_consts(T, p, c);
 #pragma unroll
@@ -162,7 +164,7 @@ template <class E>
 __device__ __forceinline__ void reset_lane_sampled(const Task& T, const Dev& d, bool with_dr, int i, uint64_t seed,
                                                    uint64_t epi, float* c, float* s, float* h) {
     if (with_dr && d.dr_n > 0) redraw_lane_params<E>(T, d, d.dr, i, seed, epi, c);
-    Rng g(seed, (uint32_t)i, RNG_INIT, epi);
+    Rng g(seed, d.idx0 + (uint32_t)i, RNG_INIT, epi);
     float init[E::I];
     E::sample_init(T, c, g, init);
     E::state_from_init(init, s);
@@ -310,7 +312,7 @@ __global__ __launch_bounds__(BLOCK) void k_rollout(Task T, Dev d, int k_steps, u
     for (int t = 0; t < k_steps; ++t) {
         uint64_t ta = epoch0 + (uint64_t)t;
         unsigned sub = (unsigned)(ta % SPB);
-        if (t == 0 || sub == 0) blk = Rng::philox(seed, (uint32_t)i, RNG_ACT, ta / SPB);
+        if (t == 0 || sub == 0) blk = Rng::philox(seed, d.idx0 + (uint32_t)i, RNG_ACT, ta / SPB);
 #pragma unroll
         for (int j = 0; j < E::A; ++j) {
             unsigned e = sub * E::A + j;  // wave-uniform element index
@@ -899,6 +901,12 @@ int vs_reset(vs_handle h, const float* init_state, int64_t pitch, int full, cons
     return VS_OK;
 }
 
+int vs_set_index_offset(vs_handle h, uint32_t first_global_index) {
+    if (!h) return VS_ERR_ARG;
+    h->d.idx0 = first_global_index;
+    return VS_OK;
+}
+
 int vs_set_auto_reset(vs_handle h, int on, uint64_t seed) {
     if (!h) return VS_ERR_ARG;
     h->auto_reset = on != 0;
@@ -912,6 +920,12 @@ int vs_step(vs_handle h, const float* actions, int64_t env_stride, int64_t dim_s
     HIPCHK(h, hipSetDevice(h->device));
     DISPATCH_ENV(h->type, launch_step<E>(h, actions, (long)env_stride, (long)dim_stride));
     HIPCHK(h, hipGetLastError());
+    return VS_OK;
+}
+
+int vs_seek_random(vs_handle h, uint64_t step_index) {
+    if (!h) return VS_ERR_ARG;
+    h->epoch = step_index;
     return VS_OK;
 }
 

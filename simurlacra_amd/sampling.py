@@ -1,0 +1,316 @@
+"""
+Host-side mirror of the sampling boundary: StepSequence (the result container algorithms consume,
+P/sampling/step_sequence.py:223-362), rollout() (P/sampling/rollout.py:63-342) and ParallelRolloutSampler
+(P/sampling/parallel_rollout_sampler.py:182-323).
+
+The reference distributes rollouts over a pool of worker processes, each stepping one pickled env copy
+(P/sampling/sampler_pool.py).  Here every rollout of a `sample()` call is one wavefront lane of ONE batched libvecsim
+handle on the GPU; `num_workers` is accepted for interface compatibility and ignored.  What is kept:
+  * the work list: `min_rollouts` rollouts, or every init_state / domain_param / their Cartesian product repeated
+    `ceil(min_rollouts / len)` times (parallel_rollout_sampler.py:280-304), or rollouts until `min_steps` steps are
+    collected, surplus dropped in index order (sampler_pool.py:392-469);
+  * the seeding contract: rollout number `i` of the `k`-th `sample()` call depends on `(seed, k, i)` only
+    (rollout.py:139, set_seed of P/__init__.py:135-183), never on how rollouts are grouped -- so results are identical for
+    every `num_workers` (Pyrado/tests/test_sampling.py:589-700);
+  * the result: a list of StepSequence in rollout order.
+"""
+import math
+from itertools import product
+from math import ceil
+from typing import List, Optional
+
+import numpy as np
+
+from . import _lib as L
+from .exceptions import TypeErr, ValueErr
+from .policies import DummyPolicy
+from .seeding import derive_seed, get_base_seed, set_seed
+from .wrappers import DomainRandWrapperLive, inner_env, typed_env
+
+NO_SEED = object()
+
+
+class StepSequence:
+    """Rollout container: observations [T+1, O], actions [T, A], rewards [T], optionally states [T+1, S].
+    The subset of P/sampling/step_sequence.py that samplers and on-policy algorithms touch."""
+
+    def __init__(self, *, observations, actions, rewards, states=None, time=None, rollout_info=None, env_infos=None,
+                 complete=True, done_last=True, **extra):
+        self.observations = np.asarray(observations)
+        self.actions = np.asarray(actions)
+        self.rewards = np.asarray(rewards, dtype=np.float64).reshape(-1)
+        if not (len(self.observations) == len(self.actions) + 1 == len(self.rewards) + 1):
+            raise ValueErr(msg="observations need one entry more than actions and rewards")
+        self.states = None if states is None else np.asarray(states)
+        self.time = np.asarray(time) if time is not None else None
+        self.rollout_info = rollout_info or {}
+        self.env_infos = env_infos
+        self.complete = complete
+        self.done = np.zeros(len(self.rewards), dtype=bool)
+        if len(self.done) and done_last:
+            self.done[-1] = True
+        for k, v in extra.items():
+            setattr(self, k, v)
+
+    @property
+    def length(self) -> int:
+        return len(self.rewards)
+
+    def __len__(self):
+        return self.length
+
+    def undiscounted_return(self) -> float:
+        return float(np.sum(self.rewards))
+
+    def discounted_return(self, gamma: float) -> float:
+        return float(np.sum(self.rewards * gamma ** np.arange(self.length)))
+
+    def __repr__(self):
+        return f"StepSequence(len={self.length}, return={self.undiscounted_return():.4g})"
+
+
+def rollout(env, policy, eval: bool = False, max_steps: Optional[int] = None, reset_kwargs: Optional[dict] = None,
+            stop_on_done: bool = True, seed: Optional[int] = None, sub_seed: Optional[int] = None,
+            sub_sub_seed: Optional[int] = None) -> StepSequence:
+    """One rollout of ONE environment object through its reset()/step() surface (rollout.py:63-342): the reference's
+    loop, one kernel launch per step.  For throughput use ParallelRolloutSampler, which batches rollouts as lanes."""
+    import torch
+
+    if not (isinstance(reset_kwargs, dict) or reset_kwargs is None):
+        raise TypeErr(given=reset_kwargs, expected_type=dict)
+    if max_steps is not None:
+        env.max_steps = max_steps
+    if seed is not None:
+        set_seed(seed, sub_seed, sub_sub_seed)
+    obs = env.reset(**(reset_kwargs or {}))
+    if hasattr(policy, "reset"):
+        policy.reset()
+    obs_hist, act_hist, rew_hist, state_hist, t_hist = [], [], [], [], [0.0]
+    done, t, steps = False, 0.0, 0
+    while not (done and stop_on_done) and steps < env.max_steps:
+        if np.isnan(obs).any():
+            raise ValueErr(msg="At least one observation value is NaN!")
+        with torch.no_grad():
+            act = policy(torch.from_numpy(np.asarray(obs)).to(torch.get_default_dtype()))
+        act = act.detach().cpu().numpy()
+        if np.isnan(act).any():
+            raise ValueErr(msg="At least one action value is NaN!")
+        state = env.state.copy()
+        obs_next, rew, done, _ = env.step(act)
+        obs_hist.append(np.asarray(obs))
+        act_hist.append(act)
+        rew_hist.append(rew)
+        state_hist.append(state)
+        t += env.dt
+        t_hist.append(t)
+        obs = obs_next
+        steps += 1
+    obs_hist.append(np.asarray(obs))
+    state_hist.append(env.state.copy())
+    info = dict(env_name=env.name, domain_param=env.domain_param)
+    # QCartPoleSim.reset returns the state instead of the observation (quirk Q5): keep lists when shapes differ
+    try:
+        observations = np.stack(obs_hist)
+    except ValueError:
+        observations = np.empty(len(obs_hist), dtype=object)
+        observations[:] = obs_hist
+    return StepSequence(observations=observations, actions=np.stack(act_hist), rewards=rew_hist,
+                        states=np.stack(state_hist), time=t_hist, rollout_info=info, done_last=bool(done))
+
+
+class ParallelRolloutSampler:
+    """Drop-in for P/sampling/parallel_rollout_sampler.py:182-323 with the rollouts batched on the GPU."""
+
+    def __init__(self, env, policy, num_workers: int = 1, *, min_rollouts: int = None, min_steps: int = None,
+                 show_progress_bar: bool = False, seed=NO_SEED, batch_lanes: int = 4096, chunk: int = 128):
+        if min_rollouts is None and min_steps is None:
+            raise ValueErr(msg="At least one of min_rollouts and min_steps must be given")  # SamplerBase
+        self.min_rollouts, self.min_steps = min_rollouts, min_steps
+        self.env, self.policy = env, policy
+        self.num_workers = num_workers  # ignored: lanes replace worker processes
+        self.show_progress_bar = show_progress_bar
+        if seed is NO_SEED:
+            seed = get_base_seed()
+        self._seed = seed
+        self._sample_count = -1
+        self._batch_lanes = int(batch_lanes)
+        self._chunk = int(chunk)
+        self._vecs = {}
+
+    def reinit(self, env=None, policy=None):
+        if env is not None:
+            self.env = env
+            self._vecs = {}
+        if policy is not None:
+            self.policy = policy
+
+    # ------------------------------------------------------------------------------------------------ work list
+    def work_list(self, init_states, domain_params):
+        """[(init_state | None, domain_param | None)] in rollout order (parallel_rollout_sampler.py:280-304)"""
+        n = self.min_rollouts
+        if init_states is None and domain_params is None:
+            return [(None, None)] * n
+        if init_states is not None and domain_params is None:
+            rep = ceil(n / len(init_states))
+            return [(s, None) for s in rep * list(init_states)]
+        if init_states is None:
+            rep = ceil(n / len(domain_params))
+            return [(None, d) for d in rep * list(domain_params)]
+        allcombs = list(product(init_states, domain_params))
+        rep = ceil(n / len(allcombs))
+        return rep * allcombs
+
+    def _key(self):
+        """64-bit Philox key of this sample() call: MD5-derived like set_seed(seed, sub_seed=sample_count)"""
+        if self._seed is None:
+            return int(np.random.randint(0, 2 ** 31 - 1)) << 20 | (self._sample_count & 0xFFFFF)
+        return (derive_seed(self._seed, self._sample_count, 0) << 32) | derive_seed(self._seed, self._sample_count, 1)
+
+    # ------------------------------------------------------------------------------------------------ batched run
+    def _vec_for(self, n):
+        """a libvecsim handle with n lanes configured like self.env (ctor args, task, domain params)"""
+        from .vec_env import VecSimEnv
+
+        base = inner_env(self.env)
+        key = n
+        if key not in self._vecs:
+            ctor = dict(base._ctor)
+            ctor.pop("num_envs", None)
+            ctor.pop("load_experimental_tholds", None)
+            ctor.pop("mass", None)
+            dev = ctor.pop("device", 0)
+            self._vecs[key] = VecSimEnv(base.name, n, ctor.pop("dt"), ctor.pop("max_steps"),
+                                        task_args=ctor.pop("task_args") or None, device=dev, **ctor)
+        v = self._vecs[key]
+        v.set_randomizer([])
+        v.set_params_uniform(base.domain_param)
+        return v
+
+    def _run_batch(self, work, first_index, eval):
+        """run len(work) rollouts as lanes; returns List[StepSequence] in order"""
+        import torch
+
+        n = len(work)
+        base = inner_env(self.env)
+        v = self._vec_for(n)
+        max_steps = base.max_steps
+        if max_steps == math.inf:
+            raise ValueErr(msg="ParallelRolloutSampler needs a finite env.max_steps")
+        S, O, A = v.dims["S"], v.dims["O"], v.dims["A"]
+        key = self._key()
+        # lane j of this batch is rollout number first_index + j of the sample() call: its Philox streams are keyed by that
+        # number, so the result does not depend on how the work list is cut into batches
+        lane_key = key
+        v.set_index_offset(first_index)
+        v.seek_random(0)
+        dps = [w[1] for w in work]
+        live = typed_env(self.env, DomainRandWrapperLive)
+        if any(d is not None for d in dps):
+            mat = np.tile(np.array([base.domain_param[k] for k in v.param_names], dtype=np.float32), (n, 1))
+            for j, d in enumerate(dps):
+                if d is not None:
+                    for k, val in d.items():
+                        mat[j, v.param_names.index(k)] = float(np.asarray(val).reshape(-1)[0])
+            v.set_params(mat)
+        elif live is not None:
+            v.sample_params(live.randomizer.device_specs(), seed=lane_key ^ 0xD1B54A32D192ED03)
+        inits = [w[0] for w in work]
+        v.set_auto_reset(False)
+        v.reset(seed=lane_key)  # init-space sample for every lane ...
+        if any(s is not None for s in inits):  # ... overridden by the explicit init states
+            width = {len(np.asarray(s).reshape(-1)) for s in inits if s is not None}
+            if len(width) != 1:
+                raise ValueErr(msg="all init states must have the same shape")
+            w_ = width.pop()
+            mask = np.array([s is not None for s in inits], dtype=np.uint8)
+            arr = np.zeros((n, w_), dtype=np.float32)
+            for j, s in enumerate(inits):
+                if s is not None:
+                    arr[j] = np.asarray(s, dtype=np.float32).reshape(-1)
+            v.reset(init_state=arr, mask=mask, seed=lane_key)
+        dev = f"cuda:{v.device}"
+        obs_t = v.tensor(L.VS_OBS)[:, :n]
+        rew_t, done_t, st_t = v.tensor(L.VS_REW)[0, :n], v.tensor(L.VS_DONE)[0, :n], v.tensor(L.VS_STATE)[:, :n]
+        use_fused = isinstance(self.policy, DummyPolicy)
+        obs_rec, act_rec, rew_rec, done_rec = [], [], [], []
+        state0 = st_t.t().clone()
+        alive = torch.ones(n, dtype=torch.bool, device=dev)
+        t = 0
+        if use_fused:
+            # rollout() with DummyPolicy == vs_step_random: fused steps, on-device uniform actions, lanes freeze at done
+            while t < max_steps and bool(alive.any()):
+                k = int(min(self._chunk, max_steps - t))
+                v.step_random(k, seed=lane_key ^ 0xA0761D6478BD642F, record=True)
+                rec = v.traj(k)
+                obs_rec.append(rec["obs"]); act_rec.append(rec["act"]); rew_rec.append(rec["rew"]); done_rec.append(rec["done"])
+                alive = ~done_t.bool()
+                t += k
+            obs_all = np.concatenate(obs_rec); act_all = np.concatenate(act_rec)
+            rew_all = np.concatenate(rew_rec); done_all = np.concatenate(done_rec).astype(bool)
+            final_obs = obs_t.t().cpu().numpy()
+        else:
+            policy = self.policy.to(dev) if hasattr(self.policy, "to") else self.policy
+            if hasattr(policy, "eval"):
+                policy.eval() if eval else policy.train()
+            v.use_stream(torch.cuda.current_stream().cuda_stream)
+            with torch.no_grad():
+                while t < max_steps:
+                    obs = obs_t.t()
+                    act = policy(obs).to(torch.float32).reshape(n, A).contiguous()
+                    obs_rec.append(obs.clone()); act_rec.append(act)
+                    v.step(act)
+                    rew_rec.append(rew_t.clone()); done_rec.append(done_t.clone())
+                    t += 1
+                    if t % 32 == 0 or t == max_steps:
+                        alive &= ~torch.stack(done_rec[-32:]).bool().any(dim=0)
+                        if not bool(alive.any()):
+                            break
+            v.use_stream(None)
+            obs_all = torch.stack(obs_rec).cpu().numpy(); act_all = torch.stack(act_rec).cpu().numpy()
+            rew_all = torch.stack(rew_rec).cpu().numpy(); done_all = torch.stack(done_rec).cpu().numpy().astype(bool)
+            final_obs = None
+        v.raise_on_error()
+        params = v.get(L.VS_PARAMS)
+        T = done_all.shape[0]
+        first_done = np.where(done_all.any(axis=0), done_all.argmax(axis=0), T - 1)
+        ros = []
+        for j in range(n):
+            Lj = int(first_done[j]) + 1
+            if Lj < T:
+                last = obs_all[Lj, j]  # the obs recorded before step Lj is observe(s_Lj) (frozen / still stepping)
+            elif final_obs is not None:
+                last = final_obs[j]
+            else:
+                last = obs_t[:, j].cpu().numpy()
+            observations = np.concatenate([obs_all[:Lj, j], last[None]], axis=0)
+            info = dict(env_name=base.name, domain_param={k: float(x) for k, x in zip(v.param_names, params[j])},
+                        rollout_number=first_index + j)
+            ros.append(StepSequence(observations=observations, actions=act_all[:Lj, j], rewards=rew_all[:Lj, j],
+                                    time=np.arange(Lj + 1) * base.dt, rollout_info=info,
+                                    done_last=bool(done_all[Lj - 1, j]), init_state=state0[j].cpu().numpy()))
+        return ros
+
+    def sample(self, init_states: Optional[List[np.ndarray]] = None, domain_params: Optional[List[dict]] = None,
+               eval: bool = False) -> List[StepSequence]:
+        self._sample_count += 1
+        if self.min_steps is None:
+            work = self.work_list(init_states, domain_params)
+            out = []
+            for a in range(0, len(work), self._batch_lanes):
+                out += self._run_batch(work[a:a + self._batch_lanes], a, eval)
+            return out
+        if init_states is not None:
+            raise NotImplementedError  # as in the reference (parallel_rollout_sampler.py:315-316)
+        # run_collect: rollouts in index order until min_steps (and min_rollouts) are reached, surplus dropped
+        out, steps, idx = [], 0, 0
+        guess = max(self.min_rollouts or 1, 1)
+        while True:
+            nb = int(min(self._batch_lanes, max(guess, 64)))
+            batch = self._run_batch([(None, None)] * nb, idx, eval)
+            for ro in batch:
+                out.append(ro)
+                steps += len(ro)
+                if steps >= self.min_steps and len(out) >= (self.min_rollouts or 0):
+                    return out
+            idx += nb
+            guess = max(guess, int(len(out) * (self.min_steps / max(steps, 1) - 1)) + 1)

@@ -231,6 +231,10 @@ class VecSimEnv:
             ptr = keep.ctypes.data_as(C.c_void_p)
         self._check(self._lib.vs_reset(self._h, ptr, self.n_envs, full, mp, int(seed) & (2 ** 64 - 1)), "vs_reset")
 
+    def set_index_offset(self, first_global_index=0):
+        """Global index of lane 0: random streams are keyed by (offset + lane), see include/vecsim.h."""
+        self._check(self._lib.vs_set_index_offset(self._h, int(first_global_index) & 0xFFFFFFFF), "vs_set_index_offset")
+
     def set_auto_reset(self, on=True, seed=0):
         self._check(self._lib.vs_set_auto_reset(self._h, int(bool(on)), int(seed) & (2 ** 64 - 1)), "vs_set_auto_reset")
 
@@ -250,6 +254,10 @@ class VecSimEnv:
         else:
             raise ShapeErr(given=actions, expected_match=(self.n_envs, A))
         self._check(self._lib.vs_step(self._h, C.c_void_p(actions.data_ptr()), es, ds), "vs_step")
+
+    def seek_random(self, step_index=0):
+        """Reposition the action stream of step_random (absolute step index, see include/vecsim.h)."""
+        self._check(self._lib.vs_seek_random(self._h, int(step_index)), "vs_seek_random")
 
     def step_random(self, k_steps=1, seed=0, record=False):
         if record and k_steps > self._traj_cap:

@@ -1,0 +1,204 @@
+"""GPU tests of the host-side mirror: the reference's Env surface, DomainRandWrapperLive and ParallelRolloutSampler
+running on the HIP kernels.  Shapes follow the reference's own tests: test_environments.py:83-214 (rollout / reset),
+environment_wrappers/test_domain_randomization.py:37-56, test_sampling.py:561-700 (determinism across worker counts)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import cpu_ref
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+KW = {"omo": dict(dt=0.02, max_steps=300), "bob": dict(dt=0.01, max_steps=500), "qq-su": dict(dt=0.004, max_steps=4000),
+      "qcp-su": dict(dt=0.002, max_steps=8000), "qbb": dict(dt=0.01, max_steps=500)}
+ENVS = list(KW)
+
+
+@pytest.fixture(scope="module")
+def vs():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import simurlacra_amd
+
+    return simurlacra_amd
+
+
+@pytest.mark.parametrize("name", ENVS)
+def test_single_env_surface_follows_golden_trajectory(vs, golden_dir, name):
+    """env.reset(init_state, domain_param) / env.step(act) of ONE env object against the reference trajectory"""
+    g = np.load(os.path.join(golden_dir, f"traj_{name.replace('-', '_')}.npz"))
+    env = vs.ENV_CLASSES[name](**KW[name])
+    names = list(env.get_nominal_domain_param().keys())
+    for i in (0, 5):
+        dp = dict(zip(names, g["params"][i]))
+        obs = env.reset(init_state=g["init"][i].copy(), domain_param=dp)
+        np.testing.assert_allclose(obs, g["reset_obs"][i], rtol=1e-5, atol=2e-6)  # qcp: the 4-D state (Q5)
+        assert obs.shape == g["reset_obs"][i].shape
+        assert env.curr_step == 0
+        for t in range(12):
+            env.state = g["state"][i, t].copy()  # one-step parity: follow the reference states
+            if name == "qcp-su" or name == "qbb":
+                env.vec.put(vs._lib.VS_HIDDEN, g["hidden"][i, t][None].astype(np.float32))
+            o, r, d, info = env.step(g["act"][i, t].copy())
+            assert isinstance(r, float) and isinstance(d, bool) and info == {}
+            np.testing.assert_allclose(o, g["obs"][i, t], rtol=1e-5, atol=2e-6)
+            assert r == pytest.approx(g["rew"][i, t], rel=2e-4, abs=1e-12)
+            assert d == bool(g["done"][i, t])
+            assert env.curr_step == t + 1
+        np.testing.assert_allclose(env.state, g["state"][i, 12], rtol=1e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("name", ENVS)
+def test_rollout_loop_and_init_space(vs, name):
+    """test_rollout / test_init_spaces of the reference: hand loop with scaled random actions until done, init samples in
+    the init space, observations in the obs space, states in the state space"""
+    np.random.seed(0)
+    env = vs.ENV_CLASSES[name](**KW[name])
+    for _ in range(5):
+        obs = env.reset()
+        assert env.state_space.contains(env.state)
+    obs = env.reset()
+    done, n = False, 0
+    while not done and n < 50:
+        obs, rew, done, _ = env.step(0.1 * env.act_space.sample_uniform())
+        assert env.obs_space.contains(obs) or done
+        n += 1
+    from simurlacra_amd.policies import DummyPolicy
+    from simurlacra_amd.sampling import rollout
+
+    env.max_steps = 20
+    ro = rollout(env, DummyPolicy(env.spec), eval=True, seed=0, sub_seed=0, sub_sub_seed=1)
+    assert 1 <= len(ro) <= 20 and ro.actions.shape == (len(ro), env.act_space.flat_dim)
+    ro2 = rollout(env, DummyPolicy(env.spec), eval=True, seed=0, sub_seed=0, sub_sub_seed=1)
+    assert np.array_equal(ro.rewards, ro2.rewards)  # set_seed -> same init state and actions
+    # test_reset: the same init state gives the same first observation
+    s0 = env.init_space.sample_uniform()
+    assert np.array_equal(env.reset(init_state=s0), env.reset(init_state=s0))
+
+
+def test_nan_action_raises(vs):
+    env = vs.QQubeSwingUpSim(**KW["qq-su"])
+    env.reset()
+    with pytest.raises(vs.ValueErr):
+        env.step(np.array([np.nan]))
+
+
+def test_domain_rand_wrapper_live_single_env(vs):
+    """params change at every reset unless given explicitly (environment_wrappers/test_domain_randomization.py:37-56)"""
+    vs.set_seed(0)
+    env = vs.QBallBalancerSim(**KW["qbb"])
+    w = vs.DomainRandWrapperLive(env, vs.create_default_randomizer(env))
+    w.reset()
+    p1 = w.domain_param
+    w.reset()
+    p2 = w.domain_param
+    assert p1 != p2 and p1["gravity_const"] != 9.81
+    fixed = dict(p1)
+    w.reset(domain_param=fixed)
+    assert w.domain_param == fixed
+    # the device constants follow: c_max on the device equals the host-side descriptor for the randomised plate
+    K = env.vec.get(vs._lib.VS_CONSTS)
+    assert K[0, 16] == pytest.approx(w.task.rew_fcn.c_max, rel=3e-6)
+    obs, rew, done, _ = w.step(np.array([0.5, -0.5]))
+    assert obs.shape == (8,) and 0 < rew <= 1
+
+
+def test_parallel_sampler_is_deterministic_across_workers_and_batches(vs):
+    """identical rollouts for every num_workers / batch size, different rollouts within a batch
+    (test_sampling.py:589-650), and a new draw at the next sample() call"""
+    from simurlacra_amd.policies import DummyPolicy
+    from simurlacra_amd.sampling import ParallelRolloutSampler
+
+    env = vs.BallOnBeamSim(**KW["bob"])
+    pol = DummyPolicy(env.spec)
+    res = []
+    for nw, bl in ((1, 4096), (4, 4096), (2, 5)):
+        s = ParallelRolloutSampler(env, pol, nw, min_rollouts=12, seed=0, batch_lanes=bl)
+        res.append(s.sample())
+        if nw == 1:
+            again = s.sample()
+    for other in res[1:]:
+        assert len(other) == len(res[0]) == 12
+        for a, b in zip(res[0], other):
+            assert len(a) == len(b) and np.array_equal(a.rewards, b.rewards) and np.array_equal(a.observations, b.observations)
+    lens = {len(r) for r in res[0]}
+    rets = {r.undiscounted_return() for r in res[0]}
+    assert len(rets) == 12 and len(lens) > 1  # different rollouts within one batch
+    assert any(not np.array_equal(a.rewards[:5], b.rewards[:5]) for a, b in zip(res[0], again))  # sample_count moved on
+    for r in res[0]:
+        assert r.observations.shape == (len(r) + 1, 4) and r.done[-1] and len(r) <= 500
+
+
+def test_parallel_sampler_matches_oracle_replay(vs):
+    """every StepSequence the sampler returns replays exactly through the oracle (obs == state for bob)"""
+    from simurlacra_amd.policies import DummyPolicy
+    from simurlacra_amd.sampling import ParallelRolloutSampler
+
+    env = vs.BallOnBeamSim(**KW["bob"])
+    w = vs.DomainRandWrapperLive(env, vs.create_default_randomizer(env))
+    s = ParallelRolloutSampler(w, DummyPolicy(env.spec), 8, min_rollouts=16, seed=3)
+    ros = s.sample()
+    ref = cpu_ref.make_ref("bob", **KW["bob"])
+    g_all = set()
+    for ro in ros:
+        P = np.array([[ro.rollout_info["domain_param"][k] for k in ref.param_names]])
+        g_all.add(round(float(P[0, 0]), 6))
+        for t in range(len(ro)):
+            out = ref.step(ro.observations[t][None].astype(np.float64), np.zeros((1, 0)), ro.actions[t][None].astype(np.float64),
+                           P, np.array([t]))
+            assert ro.rewards[t] == pytest.approx(out["rew"][0], rel=2e-4, abs=1e-12)
+            np.testing.assert_allclose(ro.observations[t + 1], out["state"][0], rtol=1e-5, atol=2e-5)
+            assert bool(out["done"][0]) == (t == len(ro) - 1) or abs(np.abs(out["state"][0, 0]) - P[0, 4] / 2) < 1e-4
+    assert len(g_all) == 16  # DomainRandWrapperLive: every rollout drew its own gravity
+
+
+def test_parallel_sampler_init_states_domain_params_and_min_steps(vs):
+    from simurlacra_amd.policies import DummyPolicy, IdlePolicy
+    from simurlacra_amd.sampling import ParallelRolloutSampler
+
+    env = vs.OneMassOscillatorSim(**KW["omo"])
+    inits = [np.array([-0.7, 0.0]), np.array([-0.66, 0.05])]
+    dps = [dict(mass=1.2), dict(mass=0.8), dict(mass=1.0)]
+    s = ParallelRolloutSampler(env, IdlePolicy(env.spec), 3, min_rollouts=6, seed=1)
+    ros = s.sample(init_states=inits, domain_params=dps)
+    assert len(ros) == 6
+    for ro, (ini, dp) in zip(ros, [(i, d) for i in inits for d in dps]):
+        np.testing.assert_allclose(ro.observations[0], ini, rtol=1e-6)
+        assert ro.rollout_info["domain_param"]["mass"] == pytest.approx(dp["mass"], rel=1e-6)
+        assert (ro.actions == 0).all() and len(ro) == 300  # idle policy: the oscillator stays inside, time-out
+    # a generic (non-fused) policy path equals the oracle for the idle policy
+    ref = cpu_ref.make_ref("omo", **KW["omo"])
+    P = ref.nominal_params(1)
+    P[0, 0] = 1.2
+    st = inits[0][None].astype(np.float32).astype(np.float64)
+    for t in range(50):
+        out = ref.step(st, np.zeros((1, 0)), np.zeros((1, 1)), P.astype(np.float32).astype(np.float64), np.array([t]))
+        st = out["state"]
+    np.testing.assert_allclose(ros[0].observations[50], st[0], rtol=1e-4, atol=1e-5)
+    # min_steps: rollouts in index order until the step budget is reached (run_collect)
+    s2 = ParallelRolloutSampler(env, DummyPolicy(env.spec), 2, min_steps=2000, seed=1, batch_lanes=64)
+    ros2 = s2.sample()
+    total = sum(len(r) for r in ros2)
+    assert total >= 2000 and total - len(ros2[-1]) < 2000
+    s3 = ParallelRolloutSampler(env, DummyPolicy(env.spec), 5, min_steps=2000, seed=1, batch_lanes=16)
+    ros3 = s3.sample()
+    assert len(ros3) == len(ros2) and all(np.array_equal(a.rewards, b.rewards) for a, b in zip(ros2, ros3))
+
+
+def test_index_offset_makes_shards_equal_the_whole(vs):
+    """multi-GPU layout on one GPU: two handles with index offsets 0 and N/2 reproduce one handle of N lanes"""
+    L = vs._lib
+    n = 4096
+    whole = vs.VecSimEnv("qcp-su", n, **KW["qcp-su"])
+    parts = [vs.VecSimEnv("qcp-su", n // 2, **KW["qcp-su"]) for _ in range(2)]
+    for e, off in [(whole, 0), (parts[0], 0), (parts[1], n // 2)]:
+        e.set_index_offset(off)
+        e.set_auto_reset(True, seed=5)
+        e.reset(seed=9)
+        e.step_random(300, seed=11)
+    s = whole.get(L.VS_STATE)
+    assert np.array_equal(s[: n // 2], parts[0].get(L.VS_STATE)) and np.array_equal(s[n // 2:], parts[1].get(L.VS_STATE))
+    c = whole.get(L.VS_EPSTAT_COUNT)
+    assert c.sum() > 100 and np.array_equal(c[n // 2:], parts[1].get(L.VS_EPSTAT_COUNT))

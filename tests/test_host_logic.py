@@ -1,0 +1,236 @@
+"""CPU tests of the host-side mirror of the reference interface: spaces, seeding, domain-randomisation objects,
+env descriptions (spaces / task / nominal params vs what the reference produced), wrappers, sampler work lists.
+Modelled on Pyrado/tests/test_spaces.py, test_set_seed.py, test_domain_randomization.py, test_sampling.py."""
+import json
+import os
+import pickle
+
+import numpy as np
+import pytest
+
+import simurlacra_amd as vs
+from simurlacra_amd.sampling import ParallelRolloutSampler, StepSequence
+
+KW = {"omo": dict(dt=0.02, max_steps=300), "bob": dict(dt=0.01, max_steps=500), "qq-su": dict(dt=0.004, max_steps=4000),
+      "qcp-su": dict(dt=0.002, max_steps=8000), "qbb": dict(dt=0.01, max_steps=500)}
+ENVS = list(KW)
+
+
+def make(name, **extra):
+    return vs.ENV_CLASSES[name](**KW[name], **extra)
+
+
+# ---------------------------------------------------------------------------------------------------- spaces
+def test_box_space_contains_project_sample():
+    bs = vs.BoxSpace([-1, -2], [1, 2], labels=["a", "b"])
+    assert bs.contains(np.array([1.0, -2.0]))  # inclusive bounds (Q9)
+    assert not bs.contains(np.array([1.0000001, 0.0]))
+    with pytest.raises(vs.ValueErr):
+        bs.contains(np.array([np.nan, 0.0]))
+    with pytest.raises(vs.ShapeErr):
+        bs.contains(np.zeros(3))
+    x = np.array([0.5, 0.5])
+    assert bs.project_to(x) is x  # same object when inside (box.py:180-184)
+    y = bs.project_to(np.array([3.0, -5.0]))
+    assert np.array_equal(y, [1.0, -2.0])
+    np.random.seed(0)
+    for _ in range(100):
+        assert bs.contains(bs.sample_uniform())
+    assert np.array_equal(bs.bound_abs_up, [1, 2]) and bs.flat_dim == 2
+    assert np.array_equal(vs.BoxSpace(-4.5, 4.5, shape=(1,)).bound_up, [4.5])
+
+
+def test_polar_and_compound_spaces():
+    np.random.seed(1)
+    ps = vs.Polar2DPosVelSpace(np.array([0.1, -np.pi, -0.02, -0.02]), np.array([0.11, np.pi, 0.02, 0.02]))
+    for _ in range(100):
+        s = ps.sample_uniform()
+        assert 0.1 - 1e-12 <= np.hypot(s[0], s[1]) <= 0.11 + 1e-12 and ps.contains(s)
+    cs = vs.CompoundSpace([vs.BoxSpace([-2.0], [-1.0]), vs.BoxSpace([1.0], [2.0])])
+    vals = np.array([cs.sample_uniform()[0] for _ in range(200)])
+    assert ((np.abs(vals) >= 1) & (np.abs(vals) <= 2)).all() and (vals < 0).any() and (vals > 0).any()
+    assert cs.contains(np.array([1.5])) and not cs.contains(np.array([0.0]))
+
+
+# ---------------------------------------------------------------------------------------------------- seeding
+def test_set_seed_kat(golden_dir):
+    for b, s, ss, exp in json.load(open(os.path.join(golden_dir, "set_seed.json"))):
+        assert vs.derive_seed(b, s, ss) == exp
+    assert vs.set_seed(0, 1, 1) == 3918913762 and vs.get_base_seed() == 0  # Pyrado/tests/test_set_seed.py:44
+    a = np.random.rand()
+    vs.set_seed(0, 1, 1)
+    assert np.random.rand() == a
+    assert vs.set_seed(None) is None and vs.set_seed(0.5) is None
+
+
+# ---------------------------------------------------------------------------------------------------- randomizers
+@pytest.mark.parametrize("name", ENVS)
+def test_default_randomizer_tables_match_reference(golden_dir, name):
+    tab = json.load(open(os.path.join(golden_dir, "randomizers.json")))[name]
+    env = make(name)
+    assert {k: float(v) for k, v in env.get_nominal_domain_param().items()} == tab["nominal"]
+    rz = vs.create_default_randomizer(env)
+    assert len(rz.domain_params) == len(tab["randomizer"])
+    for dp, row in zip(rz.domain_params, tab["randomizer"]):
+        assert dp.name == row["name"] and type(dp).__name__ == row["kind"]
+        spread = dp.std if row["kind"] == "NormalDomainParam" else dp.halfspan
+        assert float(dp.mean) == row["mean"] and float(spread) == pytest.approx(row["spread"], rel=1e-15)
+        assert float(dp.clip_lo) == row["clip_lo"] and float(dp.clip_up) == row["clip_up"]
+    specs = rz.device_specs()
+    assert [s[0] for s in specs] == [r["name"] for r in tab["randomizer"]]
+
+
+def test_domain_randomizer_formats():
+    import torch
+
+    env = make("omo")
+    rz = vs.create_default_randomizer(env)
+    torch.manual_seed(0)
+    rz.randomize(num_samples=3)
+    lst = rz.get_params(-1, "list", "numpy")
+    assert len(lst) == 3 and set(lst[0]) == {"mass", "stiffness", "damping"} and lst[0]["mass"].dtype == np.float32
+    dct = rz.get_params(2, "dict", "torch")
+    assert len(dct["mass"]) == 2
+    one = rz.get_params(1, "dict", "numpy")
+    assert one["mass"].shape == ()
+    torch.manual_seed(0)
+    rz.randomize(num_samples=3)
+    assert rz.get_params(1, "dict", "numpy")["mass"] == one["mass"]  # torch global RNG (Q13)
+    with pytest.raises(vs.ValueErr):
+        rz.randomize(0)
+    with pytest.raises(vs.TypeErr):
+        rz.randomize(1.5)
+    zr = vs.create_zero_var_randomizer(env)
+    zr.randomize(1)
+    assert abs(float(zr.get_params(1, "dict", "numpy")["stiffness"]) - 30.0) < 0.05
+    for dp in rz.domain_params:  # clipping (domain_parameter.py:123-124)
+        dp.adapt("clip_lo", float(dp.mean) * 2)
+    rz.randomize(5)
+    assert all(float(d["mass"]) == 2.0 for d in rz.get_params(-1, "list", "numpy"))
+
+
+# ---------------------------------------------------------------------------------------------------- env description
+@pytest.mark.parametrize("name", ENVS)
+def test_env_spaces_and_task_follow_domain_params(golden_dir, name):
+    """spaces / c_max for nominal AND randomised params equal what the reference built (quirk Q11)"""
+    g = np.load(os.path.join(golden_dir, f"reset_{name.replace('-', '_')}.npz"))
+    env = make(name)
+    names = list(env.get_nominal_domain_param().keys())
+    for i in range(g["params"].shape[0]):
+        env.domain_param = dict(zip(names, g["params"][i]))
+        np.testing.assert_allclose(env.state_space.bound_lo, g["state_lo"][i], rtol=1e-15)
+        np.testing.assert_allclose(env.state_space.bound_up, g["state_hi"][i], rtol=1e-15)
+        np.testing.assert_allclose(env.act_space.bound_up, g["act_hi"][i], rtol=1e-15)
+        if name == "bob":
+            lo = np.concatenate([env.init_space.subspace(0).bound_lo, env.init_space.subspace(1).bound_lo])
+            np.testing.assert_allclose(lo, g["init_lo"][i], rtol=1e-14)
+        else:
+            np.testing.assert_allclose(env.init_space.bound_lo, g["init_lo"][i], rtol=1e-14)
+            np.testing.assert_allclose(env.init_space.bound_up, g["init_hi"][i], rtol=1e-14)
+        if name in ("bob", "qbb"):
+            assert env.task.rew_fcn.c_max == pytest.approx(float(g["c_max"][i]), rel=1e-13)
+    assert env.name == name and env.spec.act_space == env.act_space
+    assert set(env.supported_domain_param) == set(names)
+    with pytest.raises(vs.ValueErr):
+        env.domain_param = {"no_such_param": 1.0}
+    with pytest.raises(vs.TypeErr):
+        env.domain_param = [1, 2]
+
+
+def test_env_ctor_errors_and_pickle():
+    with pytest.raises(vs.TypeErr):
+        vs.QQubeSwingUpSim(dt="a", max_steps=10)
+    with pytest.raises(vs.ValueErr):
+        vs.QQubeSwingUpSim(dt=-0.1, max_steps=10)
+    with pytest.raises(vs.ValueErr):
+        vs.QQubeSwingUpSim(dt=0.1, max_steps=0)
+    with pytest.raises(vs.TypeErr):
+        vs.QQubeSwingUpSim(dt=0.1, max_steps=10, task_args=[1])
+    env = vs.QCartPoleSwingUpSim(dt=0.002, max_steps=8000, long=True, wild_init="False")
+    assert env.domain_param["pole_mass"] == 0.23 and env.domain_param["pole_length"] == 0.641 / 2
+    assert env.init_space.bound_up[0] == 0.02
+    env.domain_param = dict(rail_length=1.0)
+    e2 = pickle.loads(pickle.dumps(env))  # ctor args + domain params (sim_base.py:115-123)
+    assert type(e2) is type(env) and e2.domain_param == env.domain_param and e2.state_space == env.state_space
+    assert env.state_space.bound_up[0] == pytest.approx(0.35) and env.state_space.bound_up[2] == 1.0
+    env.max_steps = 100
+    assert env.max_steps == 100
+    with pytest.raises(vs.TypeErr):
+        env.max_steps = 1.5
+    assert np.array_equal(env.limit_act(np.array([9.0])), [6.0])
+    o = vs.QQubeSwingUpSim(dt=0.004).observe(np.array([0.0, np.pi / 2, 1.0, 2.0]))
+    np.testing.assert_allclose(o, [0, 1, 1, 0, 1, 2], atol=1e-15)
+
+
+def test_no_gpu_means_loud_failure():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    env = make("qq-su")
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        env.reset()
+    with pytest.raises(RuntimeError, match="no HIP device"):
+        env.step(np.zeros(1))
+
+
+# ---------------------------------------------------------------------------------------------------- wrappers
+def test_wrappers_delegate():
+    env = make("bob")
+    rz = vs.create_default_randomizer(env)
+    w = vs.DomainRandWrapperLive(env, rz)
+    assert vs.inner_env(w) is env and w.name == "bob" and w.randomizer is rz
+    assert isinstance(vs.inner_env(w), vs.SimEnv) and vs.typed_env(w, vs.DomainRandWrapperLive) is w
+    assert list(vs.all_envs(w)) == [w, env]
+    w.domain_param = dict(beam_length=2.6)
+    assert env.domain_param["beam_length"] == 2.6 and w.state_space.bound_up[0] == 1.3  # SURVEY Q11 anchor
+    assert w.act_space.bound_up[0] == pytest.approx(38.259)
+    assert w.task.rew_fcn.c_max == pytest.approx(3.38531e-05, rel=1e-5)
+    assert w.max_steps == 500 and w.dt == 0.01
+    with pytest.raises(vs.TypeErr):
+        vs.DomainRandWrapperLive(object(), rz)
+    with pytest.raises(vs.TypeErr):
+        vs.DomainRandWrapperLive(env, "not a randomizer")
+
+
+# ---------------------------------------------------------------------------------------------------- sampler (host part)
+def test_sampler_work_list_and_keys():
+    from simurlacra_amd.policies import DummyPolicy
+
+    env = make("omo")
+    pol = DummyPolicy(env.spec)
+    with pytest.raises(vs.ValueErr):
+        ParallelRolloutSampler(env, pol, 2)
+    s = ParallelRolloutSampler(env, pol, 4, min_rollouts=5, seed=0)
+    assert s.work_list(None, None) == [(None, None)] * 5
+    inits = [np.array([-0.7, 0.0]), np.array([-0.66, 0.05])]
+    wl = s.work_list(inits, None)  # ceil(5/2)=3 repetitions (parallel_rollout_sampler.py:285-288)
+    assert len(wl) == 6 and wl[2][0] is inits[0] and wl[3][0] is inits[1]
+    dps = [dict(mass=1.1), dict(mass=0.9), dict(mass=1.0)]
+    wl = s.work_list(inits, dps)  # Cartesian product (:296-301)
+    assert len(wl) == 6 and wl[0] == (inits[0], dps[0]) and wl[1] == (inits[0], dps[1]) and wl[3] == (inits[1], dps[0])
+    s._sample_count = 0
+    k0 = s._key()
+    s._sample_count = 1
+    assert s._key() != k0
+    s2 = ParallelRolloutSampler(env, pol, 1, min_rollouts=5, seed=0)
+    s2._sample_count = 0
+    assert s2._key() == k0  # depends on (seed, sample_count) only, not on num_workers
+
+
+def test_step_sequence():
+    ro = StepSequence(observations=np.zeros((4, 2)), actions=np.zeros((3, 1)), rewards=[1.0, 2.0, 3.0])
+    assert len(ro) == 3 and ro.undiscounted_return() == 6.0 and ro.done.tolist() == [False, False, True]
+    assert ro.discounted_return(0.5) == 1 + 1 + 0.75
+    with pytest.raises(vs.ValueErr):
+        StepSequence(observations=np.zeros((3, 2)), actions=np.zeros((3, 1)), rewards=[1.0, 2.0, 3.0])
+
+
+def test_shard_layout():
+    from simurlacra_amd.dist import shard
+
+    assert [shard(262144, r, 8) for r in range(8)] == [(r * 32768, 32768) for r in range(8)]  # BASELINE config 4
+    parts = [shard(10, r, 4) for r in range(4)]
+    assert parts == [(0, 3), (3, 3), (6, 2), (8, 2)]
+    with pytest.raises(ValueError):
+        shard(10, 4, 4)
