@@ -1,0 +1,14 @@
+#!/bin/bash
+# rocprofv3 evidence for the default bench command: kernel-trace stats + HBM traffic counters in separate passes
+set -o pipefail
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+OUT=gpurun_out/prof_$1; mkdir -p $OUT
+ARGS="--no-cpu-baseline --steps 1000 --warmup 100"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/trace.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 bench.py $ARGS > $OUT/bench_fetch.json 2> $OUT/fetch.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 bench.py $ARGS > $OUT/bench_write.json 2> $OUT/write.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_step16m -- python3 bench.py --no-cpu-baseline --mode step --envs 16777216 --steps 30 --warmup 5 > $OUT/bench_step16m.json 2> $OUT/trace_step16m.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch_step16m -- python3 bench.py --no-cpu-baseline --mode step --envs 16777216 --steps 30 --warmup 5 > /dev/null 2> $OUT/f2.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write_step16m -- python3 bench.py --no-cpu-baseline --mode step --envs 16777216 --steps 30 --warmup 5 > /dev/null 2> $OUT/w2.err
+python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
+cat $OUT/bench_default.json
