@@ -71,8 +71,8 @@ __device__ __forceinline__ float step_reward(const Task& T, const float* c, cons
     for (int j = 0; j < E::A; ++j) ca += a_raw[j] * (T.rd[j] * a_raw[j]);  // err_a = -act
     cost += ca;
     if (E::REW == REW_QUADR) return -cost;
-    if (E::REW == REW_EXP) return expf(-cost);
-    return expf(-c[E::CMAX >= 0 ? E::CMAX : 0] * cost);
+    if (E::REW == REW_EXP) return exp_neg_fast(-cost);
+    return exp_neg_fast(-c[E::CMAX >= 0 ? E::CMAX : 0] * cost);
 }
 
 struct StepOut {
@@ -86,7 +86,11 @@ template <class E>
 __device__ __forceinline__ StepOut step_one(const Task& T, const float* c, float* s, float* h, const float* a_raw,
                                             int& step, bool& yielded, const float* ob) {
     StepOut o;
+#ifdef VS_ABLATE_REWARD  // diagnostic builds only (profiling by ablation); never defined in the shipped library
+    o.rew = a_raw[0];
+#else
     o.rew = step_reward<E>(T, c, s, a_raw);  // pre-step state, unclipped action (Q3)
+#endif
     float alo[E::A], ahi[E::A], a[E::A];
     E::act_bounds(c, alo, ahi);
     o.err = false;
@@ -96,7 +100,11 @@ __device__ __forceinline__ StepOut step_one(const Task& T, const float* c, float
         a[j] = fminf(fmaxf(a_raw[j], alo[j]), ahi[j]);  // limit_act -> BoxSpace.project_to (box.py:180-184)
         if (isnan(a_raw[j])) a[j] = a_raw[j];           // np.clip propagates NaN (fminf/fmaxf would drop it)
     }
+#ifdef VS_ABLATE_DYNAMICS
+    s[0] += a[0] * 1e-6f;
+#else
     E::dynamics(T, c, s, h, a, ob);
+#endif
     step += 1;
     float slo[E::S], shi[E::S];
     E::state_bounds(c, slo, shi);
@@ -312,7 +320,11 @@ __global__ __launch_bounds__(BLOCK) void k_rollout(Task T, Dev d, int k_steps, u
     for (int t = 0; t < k_steps; ++t) {
         uint64_t ta = epoch0 + (uint64_t)t;
         unsigned sub = (unsigned)(ta % SPB);
+#ifdef VS_ABLATE_RNG
+        blk = make_uint4(blk.x + 0x9E3779B9u * (unsigned)i, blk.y + 77u, blk.z + 5u, blk.w + 1u);
+#else
         if (t == 0 || sub == 0) blk = Rng::philox(seed, d.idx0 + (uint32_t)i, RNG_ACT, ta / SPB);
+#endif
 #pragma unroll
         for (int j = 0; j < E::A; ++j) {
             unsigned e = sub * E::A + j;  // wave-uniform element index
@@ -353,7 +365,11 @@ __global__ __launch_bounds__(BLOCK) void k_rollout(Task T, Dev d, int k_steps, u
             if (d.log_episodes) append_episode(d, fin, i, ret, step);
             frozen |= done;
         }
+#ifdef VS_ABLATE_OBSERVE
+        if (REC) { for (int j = 0; j < E::O; ++j) ob[j] = s[j % E::S]; }
+#else
         if (REC) E::observe(s, ob);
+#endif
     }
     if (!REC) E::observe(s, ob);
 #pragma unroll

@@ -55,11 +55,18 @@ __device__ __forceinline__ float fmod_2pi(float e) {
 }
 
 // the two sequential +-pi folds of RadiallySymmDesStateTask.step_rew (P/tasks/desired_state.py:152-153, Q4)
+// e > pi  <=>  2pi - e < e  and  e < -pi  <=>  -2pi - e > e, so each fold is a min / max with the reflected value
+// (identical results for every non-NaN e, ties included; a NaN state is reported through the error flag).
 __device__ __forceinline__ float fold_pi(float e) {
-    if (e > PI_F) e = TWO_PI_F - e;
-    if (e < -PI_F) e = -TWO_PI_F - e;
+    e = fminf(e, TWO_PI_F - e);
+    e = fmaxf(e, -TWO_PI_F - e);
     return e;
 }
+
+// exp(x) for x <= 0 on the reward path: v_exp_f32 on x*log2(e).  Rewards below fp32's normal range flush to 0 either way
+// (cost > 87); above that the rounding of x*log2(e) costs <= 5e-6 relative -- inside the 2e-4 reward tolerance, and
+// 2 instructions instead of the library's ~14.
+__device__ __forceinline__ float exp_neg_fast(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
 
 // sin and cos of a BOUNDED angle (every angle on the hot path is a state inside / next to its box, |x| < ~1e3):
 // 3-term Cody-Waite reduction by pi/2 with FMAs (exact products), then the Cephes minimax polynomials on [-pi/4, pi/4].
