@@ -115,6 +115,7 @@ def main():
     ap.add_argument("--chunk", type=int, default=100, help="env steps per launch in fused mode")
     ap.add_argument("--record", type=int, default=1)
     ap.add_argument("--per-env-params", type=int, default=1, help="1: per-env constants [K][N] (DR-capable), 0: broadcast")
+    ap.add_argument("--graph", type=int, default=0, help="step mode: capture `chunk` policy+step iterations in one hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args()
@@ -155,17 +156,39 @@ def main():
     steps = n_launch * chunk if args.mode == "fused" else args.steps
     act_hi = {"omo": 30.0, "bob": 29.43, "qq-su": 4.5, "qcp-su": 6.0, "qbb": 3.0}[args.env]
 
+    graph = None
+
+    def policy_and_step():
+        act = (torch.rand(n, d["A"], device=f"cuda:{local_rank}") * 2 - 1) * act_hi  # DummyPolicy on the GPU
+        env.step(act)
+
     def run(k_steps):
         if args.mode == "fused":
             for _ in range((k_steps + chunk - 1) // chunk):
                 env.step_random(chunk, seed=args.seed + 3, record=bool(args.record))
+        elif graph is not None:
+            for _ in range((k_steps + chunk - 1) // chunk):
+                graph.replay()
         else:
             for _ in range(k_steps):
-                act = (torch.rand(n, d["A"], device=f"cuda:{local_rank}") * 2 - 1) * act_hi
-                env.step(act)
+                policy_and_step()
 
     if args.mode == "step":
         env.use_stream(torch.cuda.current_stream().cuda_stream)
+        if args.graph:
+            # launch-bound inner loop -> one hipGraph of `chunk` (policy, vs_step) pairs; vs_step takes no host-side
+            # counter, so replaying the captured launches is exact
+            side = torch.cuda.Stream()
+            env.use_stream(side.cuda_stream)  # before the capture starts: stream switches synchronise
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    policy_and_step()
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                for _ in range(chunk):
+                    policy_and_step()
+            steps = n_launch * chunk
     run(max(args.warmup, 1))
     env.sync()
     torch.cuda.synchronize()
@@ -215,6 +238,7 @@ def main():
             "config": {"workload": f"{args.env} x {n} envs per GPU, dt {kw['dt']}, max_steps {kw['max_steps']}, uniform random "
                                    f"policy on device, auto-reset, mode={args.mode}"
                                    + (f", {chunk} steps/launch, record={args.record}" if args.mode == "fused" else "")
+                                   + (f", hipGraph of {chunk} (policy, step) pairs" if graph is not None else "")
                                    + (", per-env constants" if args.per_env_params else ", broadcast constants"),
                        "envs_per_gpu": n, "env": args.env, "mode": args.mode, "chunk": chunk, "record": args.record,
                        "parallelism": f"env-shard x{world}"},

@@ -816,7 +816,10 @@ int vs_destroy(vs_handle h) {
 
 int vs_set_stream(vs_handle h, void* s) {
     if (!h) return VS_ERR_ARG;
-    HIPCHK(h, hipStreamSynchronize(h->stream));
+    // the caller orders work across streams (events / torch stream semantics); a capturing stream must not be synced
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(h->stream, &st) != hipSuccess) (void)hipGetLastError();
+    if (st == hipStreamCaptureStatusNone) HIPCHK(h, hipStreamSynchronize(h->stream));
     h->stream = s ? (hipStream_t)s : h->own_stream;
     return VS_OK;
 }
@@ -932,8 +935,14 @@ int vs_set_auto_reset(vs_handle h, int on, uint64_t seed) {
 
 int vs_step(vs_handle h, const float* actions, int64_t env_stride, int64_t dim_stride) {
     if (!h || !actions) return fail(h, VS_ERR_ARG, "vs_step: NULL argument");
-    if (!is_device_ptr(actions)) return fail(h, VS_ERR_ARG, "vs_step: actions must be device memory");
-    HIPCHK(h, hipSetDevice(h->device));
+    // while the stream is being captured into a hipGraph only the launch itself may be issued (pointer queries and
+    // device switches invalidate the capture); the pointer was validated by the eager warm-up call
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(h->stream, &st) != hipSuccess) (void)hipGetLastError();
+    if (st == hipStreamCaptureStatusNone) {
+        if (!is_device_ptr(actions)) return fail(h, VS_ERR_ARG, "vs_step: actions must be device memory");
+        HIPCHK(h, hipSetDevice(h->device));
+    }
     DISPATCH_ENV(h->type, launch_step<E>(h, actions, (long)env_stride, (long)dim_stride));
     HIPCHK(h, hipGetLastError());
     return VS_OK;

@@ -202,3 +202,36 @@ def test_index_offset_makes_shards_equal_the_whole(vs):
     assert np.array_equal(s[: n // 2], parts[0].get(L.VS_STATE)) and np.array_equal(s[n // 2:], parts[1].get(L.VS_STATE))
     c = whole.get(L.VS_EPSTAT_COUNT)
     assert c.sum() > 100 and np.array_equal(c[n // 2:], parts[1].get(L.VS_EPSTAT_COUNT))
+
+
+def test_vs_step_replays_exactly_from_a_hip_graph(vs):
+    """launch-bound policy-in-the-loop stepping captured in a hipGraph (torch.cuda.CUDAGraph): the replayed launches give
+    the same states as eager launches, auto-reset included (vs_step takes no host-side counter)"""
+    L = vs._lib
+    n, k = 8192, 16
+    rng = np.random.default_rng(0)
+    acts = torch.from_numpy(rng.uniform(-30, 30, (3 * k, n, 1)).astype(np.float32)).cuda()
+    eager = vs.VecSimEnv("omo", n, **KW["omo"])
+    graphed = vs.VecSimEnv("omo", n, **KW["omo"])
+    for e in (eager, graphed):
+        e.set_auto_reset(True, seed=4)
+        e.reset(seed=2)
+    for t in range(3 * k):
+        eager.step(acts[t])
+    buf = torch.zeros(k, n, 1, device="cuda")
+    side = torch.cuda.Stream()
+    graphed.use_stream(side.cuda_stream)  # before the capture starts: stream switches synchronise
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        for t in range(k):
+            graphed.step(buf[t])
+    graphed.reset(seed=2)  # the capture itself did not execute anything; start from the same state
+    for rep in range(3):
+        buf.copy_(acts[rep * k:(rep + 1) * k])
+        g.replay()
+    torch.cuda.synchronize()
+    graphed.use_stream(None)
+    for which in (L.VS_STATE, L.VS_STEPCOUNT, L.VS_RETURNS, L.VS_EPSTAT_COUNT, L.VS_EPSTAT_RETSUM):
+        assert np.array_equal(eager.get(which), graphed.get(which))
+    assert eager.get(L.VS_EPSTAT_COUNT).sum() > 500  # short OMO episodes: auto-resets happened inside the graph
