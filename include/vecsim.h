@@ -177,6 +177,20 @@ int vs_set_traj_capacity(vs_handle h, int t_max);
 int vs_set_episode_log(vs_handle h, int on);
 int vs_clear_episodes(vs_handle h);
 
+/* ---- mixed batches (BASELINE config 5): several env families stepped by ONE launch ----
+ * A mixed handle groups up to 5 ordinary handles on one device (lanes sorted by type: each handle is one contiguous
+ * segment).  A workgroup belongs to one segment, so the env-type dispatch is uniform per workgroup / wavefront.
+ * Parameters, resets and data access go through the member handles; the mixed handle only fuses the launches.  All
+ * members share the stream of the first one and must agree on auto-reset. */
+typedef struct vs_mixed* vs_mixed_handle;
+int vs_mixed_create(const vs_handle* handles, int n, vs_mixed_handle* out);
+int vs_mixed_destroy(vs_mixed_handle m);
+const char* vs_mixed_last_error(vs_mixed_handle m);
+/* vs_step_random / vs_step for every member in one kernel; actions[q] etc. are the arguments of vs_step for member q */
+int vs_mixed_step_random(vs_mixed_handle m, uint64_t seed, int k_steps, int record);
+int vs_mixed_step(vs_mixed_handle m, const float* const* actions, const int64_t* env_strides, const int64_t* dim_strides);
+int vs_mixed_time_random(vs_mixed_handle m, uint64_t seed, int k_steps, int record, int iters, float* avg_ms);
+
 /* ---- data access ---- */
 
 void* vs_get(vs_handle h, int which);                       /* device pointer, NULL on error */

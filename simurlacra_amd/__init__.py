@@ -15,7 +15,7 @@ from .envs import (ENV_CLASSES, BallOnBeamSim, OneMassOscillatorSim, QBallBalanc
 from .exceptions import KeyErr, ShapeErr, TypeErr, ValueErr  # noqa: F401
 from .seeding import derive_seed, get_base_seed, set_seed  # noqa: F401
 from .spaces import BoxSpace, CompoundSpace, EnvSpec, Polar2DPosVelSpace  # noqa: F401
-from .vec_env import VecSimEnv, env_dims, nominal_params, param_names  # noqa: F401
+from .vec_env import MixedVecSimEnv, VecSimEnv, env_dims, nominal_params, param_names  # noqa: F401
 from .wrappers import DomainRandWrapper, DomainRandWrapperLive, EnvWrapper, all_envs, inner_env, typed_env  # noqa: F401
 
 inf = float("inf")

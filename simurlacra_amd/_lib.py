@@ -51,6 +51,12 @@ _SIGNATURES = {
     "vs_set_traj_capacity": (C.c_int, [_P, C.c_int]),
     "vs_set_episode_log": (C.c_int, [_P, C.c_int]),
     "vs_clear_episodes": (C.c_int, [_P]),
+    "vs_mixed_create": (C.c_int, [C.POINTER(_P), C.c_int, C.POINTER(_P)]),
+    "vs_mixed_destroy": (C.c_int, [_P]),
+    "vs_mixed_last_error": (C.c_char_p, [_P]),
+    "vs_mixed_step_random": (C.c_int, [_P, C.c_uint64, C.c_int, C.c_int]),
+    "vs_mixed_step": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "vs_mixed_time_random": (C.c_int, [_P, C.c_uint64, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "vs_get": (_P, [_P, C.c_int]),
     "vs_copy_to_host": (C.c_int, [_P, C.c_int, _P]),
     "vs_copy_from_host": (C.c_int, [_P, C.c_int, _P]),

@@ -228,9 +228,9 @@ __device__ __forceinline__ void auto_reset(const Task& T, const Dev& d, bool fin
 // vs_step: one fused SimPyEnv.step per lane.  AR = auto-reset of finished lanes inside the same launch.
 // No host-side counter enters the kernel: replaying a captured hipGraph of vs_step launches is safe.
 template <class E, bool UNI, bool AR>
-__global__ __launch_bounds__(BLOCK) void k_step(Task T, Dev d, const float* __restrict__ act, long env_stride,
-                                                long dim_stride, uint64_t seed) {
-    int i = blockIdx.x * BLOCK + threadIdx.x;
+__device__ __forceinline__ void step_body(const Task& T, const Dev& d, const float* __restrict__ act, long env_stride,
+                                          long dim_stride, uint64_t seed, int block) {
+    int i = block * BLOCK + threadIdx.x;
     if (i >= d.ld) return;
     const size_t ld = d.ld;
     float c[E::K], s[E::S], h[E::H > 0 ? E::H : 1], a[E::A];
@@ -281,6 +281,12 @@ __global__ __launch_bounds__(BLOCK) void k_step(Task T, Dev d, const float* __re
     if (E::HAS_FINAL) d.yielded[i] = yielded;
 }
 
+template <class E, bool UNI, bool AR>
+__global__ __launch_bounds__(BLOCK) void k_step(Task T, Dev d, const float* __restrict__ act, long env_stride,
+                                                long dim_stride, uint64_t seed) {
+    step_body<E, UNI, AR>(T, d, act, env_stride, dim_stride, seed, (int)blockIdx.x);
+}
+
 // ---------------------------------------------------------------------------------------------------- rollout kernel
 // vs_step_random: rollout() with DummyPolicy (rollout.py:185-239, dummy.py:77-84) -- k env steps per launch, state,
 // hidden state and constants stay in registers; only the per-step records stream to HBM when REC.
@@ -288,9 +294,9 @@ __global__ __launch_bounds__(BLOCK) void k_step(Task T, Dev d, const float* __re
 // Actions: Philox4x32-10 keyed by `seed`, counter (env, RNG_ACT, absolute step / SPB); one block feeds SPB = 4 / A
 // consecutive steps (the block boundary is wave-uniform because it depends on the launch-global step index only).
 template <class E, bool UNI, bool AR, bool REC>
-__global__ __launch_bounds__(BLOCK) void k_rollout(Task T, Dev d, int k_steps, uint64_t seed, uint64_t reset_seed,
-                                                   uint64_t epoch0) {
-    int i = blockIdx.x * BLOCK + threadIdx.x;
+__device__ __forceinline__ void rollout_body(const Task& T, const Dev& d, int k_steps, uint64_t seed, uint64_t reset_seed,
+                                             uint64_t epoch0, int block) {
+    int i = block * BLOCK + threadIdx.x;
     if (i >= d.ld) return;
     const size_t ld = d.ld;
     bool valid = i < d.n;
@@ -388,6 +394,58 @@ __global__ __launch_bounds__(BLOCK) void k_rollout(Task T, Dev d, int k_steps, u
     d.es_count[i] = es.count;
     d.es_retsum[i] = es.retsum;
     d.es_lensum[i] = es.lensum;
+}
+
+template <class E, bool UNI, bool AR, bool REC>
+__global__ __launch_bounds__(BLOCK) void k_rollout(Task T, Dev d, int k_steps, uint64_t seed, uint64_t reset_seed,
+                                                   uint64_t epoch0) {
+    rollout_body<E, UNI, AR, REC>(T, d, k_steps, seed, reset_seed, epoch0, (int)blockIdx.x);
+}
+
+// ---------------------------------------------------------------------------------------------------- mixed batches
+// BASELINE config 5: several env families in ONE launch.  Lanes are sorted by type (one segment = one ordinary handle),
+// a workgroup belongs to exactly one segment, so the type switch is uniform per workgroup and every wavefront takes
+// a single branch.  The bodies are the very functions the single-type kernels run: results are bit-identical.
+constexpr int MAX_SEG = 5;
+struct Seg {
+    int type;
+    int block_end;  // exclusive prefix of workgroups
+    Task T;
+    Dev d;
+    const float* act;
+    long env_stride, dim_stride;
+    uint64_t reset_seed, epoch0;
+};
+struct Segs {
+    int n;
+    Seg s[MAX_SEG];
+};
+
+#define MIXED_DISPATCH(type, ...)                                 \
+    switch (type) {                                               \
+        case VS_ENV_OMO: { using E = Omo; __VA_ARGS__; } break;     \
+        case VS_ENV_BOB: { using E = Bob; __VA_ARGS__; } break;     \
+        case VS_ENV_QQ_SU: { using E = QQ; __VA_ARGS__; } break;    \
+        case VS_ENV_QCP_SU: { using E = Qcp; __VA_ARGS__; } break;  \
+        default: { using E = Qbb; __VA_ARGS__; } break;             \
+    }
+
+template <bool AR, bool REC>
+__global__ __launch_bounds__(BLOCK) void k_rollout_mixed(const Segs* __restrict__ segs, int k_steps, uint64_t seed) {
+    int b = blockIdx.x, q = 0, first = 0;
+    int n = segs->n;
+    while (q < n - 1 && b >= segs->s[q].block_end) first = segs->s[q++].block_end;
+    const Seg& sg = segs->s[q];
+    MIXED_DISPATCH(sg.type, (rollout_body<E, false, AR, REC>(sg.T, sg.d, k_steps, seed, sg.reset_seed, sg.epoch0, b - first)));
+}
+
+template <bool AR>
+__global__ __launch_bounds__(BLOCK) void k_step_mixed(const Segs* __restrict__ segs) {
+    int b = blockIdx.x, q = 0, first = 0;
+    int n = segs->n;
+    while (q < n - 1 && b >= segs->s[q].block_end) first = segs->s[q++].block_end;
+    const Seg& sg = segs->s[q];
+    MIXED_DISPATCH(sg.type, (step_body<E, false, AR>(sg.T, sg.d, sg.act, sg.env_stride, sg.dim_stride, sg.reset_seed, b - first)));
 }
 
 // -------------------------------------------------------------------------------------------- params / reset kernels
@@ -692,6 +750,44 @@ static void launch_rollout(vs_handle h, int k, uint64_t seed, uint64_t ep, bool 
 #undef LR
 }
 
+struct vs_mixed {
+    int n = 0;
+    vs_handle sub[MAX_SEG]{};
+    Segs host{};
+    Segs* dev = nullptr;
+    int total_blocks = 0;
+    std::string err;
+};
+
+static int mixed_upload(vs_mixed* m, const float* const* acts, const int64_t* env_strides, const int64_t* dim_strides,
+                        int k_steps) {
+    int blocks = 0;
+    vs_handle h0 = m->sub[0];
+    for (int q = 0; q < m->n; ++q) {
+        vs_handle h = m->sub[q];
+        Seg& sg = m->host.s[q];
+        blocks += (h->d.ld + BLOCK - 1) / BLOCK;
+        sg.type = h->type;
+        sg.block_end = blocks;
+        sg.T = h->task;
+        sg.d = h->d;
+        sg.act = acts ? acts[q] : nullptr;
+        sg.env_stride = env_strides ? (long)env_strides[q] : 0;
+        sg.dim_stride = dim_strides ? (long)dim_strides[q] : 0;
+        sg.reset_seed = h->ar_seed;
+        sg.epoch0 = h->epoch;
+        h->epoch += (uint64_t)k_steps;
+    }
+    m->host.n = m->n;
+    m->total_blocks = blocks;
+    // the segment table travels through device memory (kernel arguments are capped at 4 KB); hipMemcpyAsync from the
+    // pageable host copy is ordered on the stream before the launch that reads it
+    hipError_t e = hipMemcpyAsync(m->dev, &m->host, sizeof(Segs), hipMemcpyHostToDevice, h0->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h0->stream);  // host.s is rewritten by the next call
+    if (e != hipSuccess) { m->err = std::string("mixed_upload: ") + hipGetErrorString(e); return VS_ERR_HIP; }
+    return VS_OK;
+}
+
 extern "C" {
 
 int vs_version(void) { return 100; }
@@ -987,6 +1083,94 @@ int vs_set_episode_log(vs_handle h, int on) {
     if (!h) return VS_ERR_ARG;
     h->d.log_episodes = on != 0;
     return VS_OK;
+}
+
+int vs_mixed_create(const vs_handle* handles, int n, vs_mixed_handle* out) {
+    if (!handles || !out || n < 1 || n > MAX_SEG) return fail(nullptr, VS_ERR_ARG, "vs_mixed_create: need 1..5 handles");
+    *out = nullptr;
+    for (int q = 0; q < n; ++q) {
+        if (!handles[q]) return fail(nullptr, VS_ERR_ARG, "vs_mixed_create: NULL handle");
+        if (handles[q]->device != handles[0]->device) return fail(nullptr, VS_ERR_ARG, "vs_mixed_create: handles on different devices");
+        if (handles[q]->auto_reset != handles[0]->auto_reset) return fail(nullptr, VS_ERR_ARG, "vs_mixed_create: handles differ in auto-reset");
+    }
+    vs_mixed* m = new (std::nothrow) vs_mixed();
+    if (!m) return fail(nullptr, VS_ERR_HIP, "vs_mixed_create: out of host memory");
+    m->n = n;
+    for (int q = 0; q < n; ++q) {
+        m->sub[q] = handles[q];
+        handles[q]->stream = handles[0]->stream;  // one launch, one stream
+    }
+    if (hipSetDevice(handles[0]->device) != hipSuccess || hipMalloc((void**)&m->dev, sizeof(Segs)) != hipSuccess) {
+        delete m;
+        return fail(nullptr, VS_ERR_HIP, "vs_mixed_create: hipMalloc failed");
+    }
+    *out = m;
+    return VS_OK;
+}
+
+int vs_mixed_destroy(vs_mixed_handle m) {
+    if (!m) return VS_OK;
+    if (m->dev) (void)hipFree(m->dev);
+    delete m;
+    return VS_OK;
+}
+
+const char* vs_mixed_last_error(vs_mixed_handle m) { return m ? m->err.c_str() : ""; }
+
+int vs_mixed_step_random(vs_mixed_handle m, uint64_t seed, int k_steps, int record) {
+    if (!m || k_steps < 1) return VS_ERR_ARG;
+    for (int q = 0; q < m->n; ++q) {
+        if (record && k_steps > m->sub[q]->traj_cap) { m->err = "vs_mixed_step_random: k_steps exceeds a segment's vs_set_traj_capacity"; return VS_ERR_STATE; }
+        if (m->sub[q]->auto_reset != m->sub[0]->auto_reset) { m->err = "vs_mixed_step_random: segments differ in auto-reset"; return VS_ERR_STATE; }
+    }
+    if (hipSetDevice(m->sub[0]->device) != hipSuccess) return VS_ERR_HIP;
+    int rc = mixed_upload(m, nullptr, nullptr, nullptr, k_steps);
+    if (rc) return rc;
+    dim3 g((unsigned)m->total_blocks), b(BLOCK);
+    hipStream_t st = m->sub[0]->stream;
+    bool ar = m->sub[0]->auto_reset;
+    if (ar) { if (record) hipLaunchKernelGGL((k_rollout_mixed<true, true>), g, b, 0, st, (const Segs*)m->dev, k_steps, seed);
+              else hipLaunchKernelGGL((k_rollout_mixed<true, false>), g, b, 0, st, (const Segs*)m->dev, k_steps, seed); }
+    else { if (record) hipLaunchKernelGGL((k_rollout_mixed<false, true>), g, b, 0, st, (const Segs*)m->dev, k_steps, seed);
+           else hipLaunchKernelGGL((k_rollout_mixed<false, false>), g, b, 0, st, (const Segs*)m->dev, k_steps, seed); }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { m->err = hipGetErrorString(e); return VS_ERR_HIP; }
+    return VS_OK;
+}
+
+int vs_mixed_step(vs_mixed_handle m, const float* const* actions, const int64_t* env_strides, const int64_t* dim_strides) {
+    if (!m || !actions || !env_strides || !dim_strides) return VS_ERR_ARG;
+    for (int q = 0; q < m->n; ++q)
+        if (!actions[q] || !is_device_ptr(actions[q])) { m->err = "vs_mixed_step: actions must be device memory"; return VS_ERR_ARG; }
+    if (hipSetDevice(m->sub[0]->device) != hipSuccess) return VS_ERR_HIP;
+    int rc = mixed_upload(m, actions, env_strides, dim_strides, 0);
+    if (rc) return rc;
+    dim3 g((unsigned)m->total_blocks), b(BLOCK);
+    hipStream_t st = m->sub[0]->stream;
+    if (m->sub[0]->auto_reset) hipLaunchKernelGGL((k_step_mixed<true>), g, b, 0, st, (const Segs*)m->dev);
+    else hipLaunchKernelGGL((k_step_mixed<false>), g, b, 0, st, (const Segs*)m->dev);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { m->err = hipGetErrorString(e); return VS_ERR_HIP; }
+    return VS_OK;
+}
+
+int vs_mixed_time_random(vs_mixed_handle m, uint64_t seed, int k_steps, int record, int iters, float* avg_ms) {
+    if (!m || !avg_ms || iters < 1) return VS_ERR_ARG;
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return VS_ERR_HIP;
+    int rc = vs_mixed_step_random(m, seed, k_steps, record);
+    hipStream_t st = m->sub[0]->stream;
+    if (rc == VS_OK) {
+        (void)hipEventRecord(e0, st);
+        for (int it = 0; it < iters && rc == VS_OK; ++it) rc = vs_mixed_step_random(m, seed, k_steps, record);
+        (void)hipEventRecord(e1, st);
+        float ms = 0.f;
+        if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) rc = VS_ERR_HIP;
+        *avg_ms = ms / (float)iters;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return rc;
 }
 
 int vs_clear_episodes(vs_handle h) {

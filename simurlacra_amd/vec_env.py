@@ -378,3 +378,71 @@ class VecSimEnv:
             rc = self._lib.vs_time_step_kernel(self._h, 1, None, 0, 0, int(k_steps), int(bool(record)), int(iters), C.byref(ms))
         self._check(rc, "vs_time_step_kernel")
         return float(ms.value)
+
+
+class MixedVecSimEnv:
+    """Several env families stepped by ONE launch (BASELINE config 5): a group of VecSimEnv handles on one device, lanes
+    sorted by type (each member is one contiguous segment).  Parameters, resets and data access stay with the members."""
+
+    def __init__(self, members):
+        members = list(members)
+        if not 1 <= len(members) <= 5 or not all(isinstance(m, VecSimEnv) for m in members):
+            raise TypeErr(given=members, expected_type="1..5 VecSimEnv")
+        self.members = members
+        self._lib = L.load()
+        arr = (C.c_void_p * len(members))(*[m._h for m in members])
+        h = C.c_void_p()
+        rc = self._lib.vs_mixed_create(arr, len(members), C.byref(h))
+        if rc != 0:
+            raise RuntimeError(f"vs_mixed_create failed ({rc}): {self._lib.vs_last_error(None).decode()}")
+        self._h = h
+        off = 0
+        for m in members:  # global lane indices: independent random streams across the segments
+            m.set_index_offset(off)
+            off += m.n_envs
+
+    @property
+    def n_envs(self):
+        return sum(m.n_envs for m in self.members)
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed ({rc}): {self._lib.vs_mixed_last_error(self._h).decode()}")
+
+    def step_random(self, k_steps=1, seed=0, record=False):
+        if record:
+            for m in self.members:
+                if k_steps > m._traj_cap:
+                    m._check(m._lib.vs_set_traj_capacity(m._h, int(k_steps)), "vs_set_traj_capacity")
+                    m._traj_cap = int(k_steps)
+        self._check(self._lib.vs_mixed_step_random(self._h, int(seed) & (2 ** 64 - 1), int(k_steps), int(bool(record))),
+                    "vs_mixed_step_random")
+
+    def step(self, actions):
+        """actions: one torch CUDA tensor [N_q, A_q] per member"""
+        n = len(self.members)
+        ptrs = (C.c_void_p * n)(*[a.data_ptr() for a in actions])
+        es = (C.c_int64 * n)(*[a.stride(0) for a in actions])
+        ds = (C.c_int64 * n)(*[a.stride(1) if a.dim() == 2 else 0 for a in actions])
+        self._keep = actions
+        self._check(self._lib.vs_mixed_step(self._h, ptrs, es, ds), "vs_mixed_step")
+
+    def time_random(self, k_steps, record=False, iters=20, seed=0):
+        ms = C.c_float()
+        self._check(self._lib.vs_mixed_time_random(self._h, int(seed), int(k_steps), int(bool(record)), int(iters), C.byref(ms)),
+                    "vs_mixed_time_random")
+        return float(ms.value)
+
+    def sync(self):
+        self.members[0].sync()
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.vs_mixed_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

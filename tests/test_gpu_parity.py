@@ -562,3 +562,51 @@ def test_fast_sincos_accuracy_through_observe(vs):
     err = np.abs(o[:, :4] - exp).max()
     assert err < 2.0e-7, err
     env.close()
+
+
+@pytest.mark.parametrize("auto_reset", [False, True])
+def test_mixed_batch_equals_separate_handles(vs, auto_reset):
+    """BASELINE config 5 (QQube + QCartPole + BallOnBeam in one launch, lanes sorted by type): the mixed launch runs the
+    same per-type bodies, so every member ends bit-identical to a stand-alone handle stepped on its own"""
+    L = vs._lib
+    names, sizes = ["qq-su", "qcp-su", "bob"], [3000, 1111, 2048]  # ragged: segments end inside a workgroup
+    mixed_members = [vs.VecSimEnv(nm, n, **KW[nm]) for nm, n in zip(names, sizes)]
+    solo = [vs.VecSimEnv(nm, n, **KW[nm]) for nm, n in zip(names, sizes)]
+    mixed = vs.MixedVecSimEnv(mixed_members)
+    off = 0
+    for a, b in zip(mixed_members, solo):
+        b.set_index_offset(off)
+        off += b.n_envs
+        for e in (a, b):
+            e.set_params(np.tile(vs.nominal_params(e.name), (e.n_envs, 1)))
+            e.set_auto_reset(auto_reset, seed=21)
+            e.reset(seed=5)
+    mixed.step_random(150, seed=9, record=True)
+    for b in solo:
+        b.step_random(150, seed=9, record=True)
+    for a, b in zip(mixed_members, solo):
+        for which in (L.VS_STATE, L.VS_OBS, L.VS_HIDDEN, L.VS_REW, L.VS_DONE, L.VS_STEPCOUNT, L.VS_RETURNS, L.VS_EPSTAT_COUNT):
+            assert np.array_equal(a.get(which), b.get(which)), (a.name, which)
+        ta, tb = a.traj(150), b.traj(150)
+        for k in ta:
+            assert np.array_equal(ta[k], tb[k])
+    # policy-in-the-loop variant: one launch for three action tensors
+    rng = np.random.default_rng(3)
+    acts = [dev(rng.uniform(-5, 5, (n, 1))) for n in sizes]
+    mixed.step(acts)
+    for b, act in zip(solo, acts):
+        b.step(act)
+    for a, b in zip(mixed_members, solo):
+        assert np.array_equal(a.get(L.VS_STATE), b.get(L.VS_STATE)) and np.array_equal(a.get(L.VS_REW), b.get(L.VS_REW))
+    # and against the oracle for the QCartPole segment
+    ref = cpu_ref.make_ref("qcp-su", **KW["qcp-su"])
+    m = mixed_members[1]
+    s0, h0, c0 = m.get(L.VS_STATE).astype(np.float64), m.get(L.VS_HIDDEN).astype(np.float64), m.get(L.VS_STEPCOUNT)
+    act = f32(rng.uniform(-7, 7, (sizes[1], 1)))
+    m.set_auto_reset(False)
+    mixed_members[0].set_auto_reset(False)
+    mixed_members[2].set_auto_reset(False)
+    mixed.step([dev(np.zeros((sizes[0], 1))), dev(act), dev(np.zeros((sizes[2], 1)))])
+    exp = ref.step(s0, h0, act.astype(np.float64), ref.nominal_params(sizes[1]).astype(np.float32).astype(np.float64), c0)
+    assert_state_close(ref, m.get(L.VS_STATE), exp["state"], ref.nominal_params(sizes[1]))
+    mixed.close()
