@@ -368,6 +368,9 @@ class VecSimEnv:
 
     def time_step_kernel(self, iters=100, actions=None, k_steps=1, record=False):
         """Average device time [ms] per launch of the step kernel (hipEvents on the kernel's stream)."""
+        if record and k_steps > self._traj_cap:
+            self._check(self._lib.vs_set_traj_capacity(self._h, int(k_steps)), "vs_set_traj_capacity")
+            self._traj_cap = int(k_steps)
         ms = C.c_float()
         if actions is not None:
             A = self.dims["A"]
@@ -428,6 +431,11 @@ class MixedVecSimEnv:
         self._check(self._lib.vs_mixed_step(self._h, ptrs, es, ds), "vs_mixed_step")
 
     def time_random(self, k_steps, record=False, iters=20, seed=0):
+        if record:
+            for m in self.members:
+                if k_steps > m._traj_cap:
+                    m._check(m._lib.vs_set_traj_capacity(m._h, int(k_steps)), "vs_set_traj_capacity")
+                    m._traj_cap = int(k_steps)
         ms = C.c_float()
         self._check(self._lib.vs_mixed_time_random(self._h, int(seed), int(k_steps), int(bool(record)), int(iters), C.byref(ms)),
                     "vs_mixed_time_random")
