@@ -230,6 +230,21 @@ def main():
             units = n
             kname = "k_step"
         achieved = b_per * units / (ms * 1e-3) / 1e9
+        # HBM bytes per launch from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 passes of this very
+        # command; gfx950 correction applied) -- measured once per round and committed under profiles/
+        traffic, traffic_src = None, None
+        try:
+            import glob
+
+            tf = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))[-1]
+            tab = json.load(open(tf))
+            if (args.mode == "fused" and args.env == "qq-su" and n == 65536 and chunk == 100 and args.record == 1
+                    and args.per_env_params == 1):
+                traffic, traffic_src = tab["fused_default"]["traffic_bytes_per_launch"], os.path.basename(tf)
+            elif args.mode == "step" and args.env == "qq-su" and n == 16777216:
+                traffic, traffic_src = tab["step_16m"]["traffic_bytes_per_launch"], os.path.basename(tf)
+        except Exception:
+            pass
         out = {
             "metric": "env-steps/sec whole node, 65 536 QQubeSwingUpSim envs, random policy",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
@@ -243,8 +258,11 @@ def main():
                        "envs_per_gpu": n, "env": args.env, "mode": args.mode, "chunk": chunk, "record": args.record,
                        "parallelism": f"env-shard x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": kname,
-                         "kernel_ms": ms, "alg_bytes_per_env_step": b_per, "env_steps_per_launch": units},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes/launch (PMC)",
+                         "traffic_source": traffic_src, "alg_bytes_per_launch": b_per * units, "kernel": kname,
+                         "kernel_ms": ms, "alg_bytes_per_env_step": b_per, "env_steps_per_launch": units,
+                         "note": "at 65 536 envs the fused kernel holds one wave per SIMD and is bound by VALU issue "
+                                 "(~270 instructions per env step and wave, DESIGN.md section 7), not by HBM"},
             "episodes": {"completed": ep["episodes"], "mean_return": ep["mean_return"], "mean_length": ep["mean_length"]},
             "nan_flags": errs,
         }

@@ -170,10 +170,6 @@ int vs_step_random(vs_handle h, uint64_t seed, int k_steps, int record);
  * steps it has taken.  vs_seek_random repositions that counter (0 = start of a fresh batch of rollouts). */
 int vs_seek_random(vs_handle h, uint64_t step_index);
 int vs_set_traj_capacity(vs_handle h, int t_max);
-/* which fused kernel vs_step_random launches: -1 automatic (default), 0 plain (one wave per 64 envs), 1 wave-specialised
- * (a dynamics wave and a record wave per 64 envs, exchanging through LDS; for batches below ~2 waves per SIMD).
- * Results are bit-identical; the automatic choice only looks at the batch size and at live randomisation. */
-int vs_set_rollout_variant(vs_handle h, int variant);
 /* Episode bookkeeping.  Always on: per-env accumulators VS_EPSTAT_* (plain per-lane adds, no atomics) -- what the
  * RCCL return gather reads.  Opt-in (vs_set_episode_log): every finished episode is also appended as (return, length,
  * env index) to the VS_EP_* ring, compacted with a wavefront ballot and one atomic per wave; that atomic is a shared

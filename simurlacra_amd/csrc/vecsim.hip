@@ -402,202 +402,6 @@ __global__ __launch_bounds__(BLOCK) void k_rollout(Task T, Dev d, int k_steps, u
     rollout_body<E, UNI, AR, REC>(T, d, k_steps, seed, reset_seed, epoch0, (int)blockIdx.x);
 }
 
-// ------------------------------------------------------------------------------------ wave-specialised rollout kernel
-// At the size of the headline metric (65 536 envs) the plain rollout kernel has exactly one wave per SIMD, and a lone
-// wave issues one instruction every ~4 cycles: the kernel is bound by single-wave issue, not by VALU throughput or HBM.
-// This variant splits the work of one env step between TWO waves that own the same 64 envs:
-//   D wave ("dynamics"):  clip -> dead zone -> integrate -> bounds / done -> auto-reset          (owns state, hidden, step)
-//   R wave ("record"):    action RNG, reward, observe, the record stores, returns / statistics   (owns a copy of the state)
-// They exchange the action (R -> D) and the next state + flags (D -> R) through double-buffered LDS slots with ONE
-// workgroup barrier per env step, so both roles stay busy all the time and every SIMD holds two waves with about half
-// the instruction stream each.  A 256-thread workgroup = 2 D waves + 2 R waves = 128 envs.
-// The arithmetic is the same device functions as k_step / k_rollout (bit-identical results); live domain randomisation
-// (constants that change inside the launch) stays on the plain kernel.
-constexpr int WS_ENVS = BLOCK / 2;
-
-template <class E, bool UNI, bool AR, bool REC>
-__global__ __launch_bounds__(BLOCK) void k_rollout_ws(Task T, Dev d, int k_steps, uint64_t seed, uint64_t reset_seed,
-                                                      uint64_t epoch0) {
-    __shared__ float l_act[2][E::A][WS_ENVS];
-    __shared__ float l_st[2][E::S][WS_ENVS];
-    __shared__ unsigned l_flags[2][WS_ENVS];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const bool role_r = wave >= 2;
-    const int le = (wave & 1) * 64 + lane;  // env slot inside the workgroup
-    const int i = blockIdx.x * WS_ENVS + le;
-    const size_t ld = d.ld;
-    const bool valid = i < d.n;
-    enum : unsigned { F_DONE = 1u, F_FAILED = 2u, F_FROZEN = 4u, F_FIN = 8u };
-    float c[E::K], s[E::S];
-    load_consts<E, UNI>(d, i, c, 0, E::KS);
-#pragma unroll
-    for (int j = 0; j < E::S; ++j) s[j] = d.state[j * ld + i];
-
-    if (!role_r) {
-        // ------------------------------------------------------------------------------------------- D wave
-        float h[E::H > 0 ? E::H : 1], a[E::A];
-#pragma unroll
-        for (int j = 0; j < E::H; ++j) h[j] = d.hidden[j * ld + i];
-        int step = d.step[i];
-        uint32_t epi = d.ep_idx[i];
-        bool frozen = !AR && d.done[i] != 0;
-        bool done = d.done[i] != 0, failed = d.failed[i] != 0;
-        float alo[E::A], ahi[E::A], slo[E::S], shi[E::S];
-        E::act_bounds(c, alo, ahi);
-        E::state_bounds(c, slo, shi);
-        __builtin_amdgcn_s_waitcnt(0x0F70);
-        __syncthreads();  // a_0 is in l_act[0]
-        for (int t = 0; t < k_steps; ++t) {
-            const int b = t & 1;
-#pragma unroll
-            for (int j = 0; j < E::A; ++j) a[j] = l_act[b][j][le];
-            bool fin = false;
-            int len = step;
-            if (!frozen) {
-                // the D half of step_one: limit_act -> _step_dynamics -> curr_step += 1 -> is_done (base.py:223-235)
-                bool err = false;
-                float ac[E::A];
-#pragma unroll
-                for (int j = 0; j < E::A; ++j) {
-                    err |= isnan(a[j]);
-                    ac[j] = fminf(fmaxf(a[j], alo[j]), ahi[j]);
-                    if (isnan(a[j])) ac[j] = a[j];
-                }
-                E::dynamics(T, c, s, h, ac, nullptr);
-                step += 1;
-                failed = false;
-#pragma unroll
-                for (int j = 0; j < E::S; ++j) {
-                    err |= isnan(s[j]);
-                    failed |= E::SYMMETRIC_BOX ? (fabsf(s[j]) > shi[j]) : ((s[j] < slo[j]) | (s[j] > shi[j]));
-                }
-                done = failed | (step >= T.max_steps);
-                if (err && valid) d.err[i] = 1;
-                fin = done && valid;
-                len = step;
-            }
-            unsigned fl = (done ? F_DONE : 0u) | (failed ? F_FAILED : 0u) | (frozen ? F_FROZEN : 0u) | (fin ? F_FIN : 0u) |
-                          ((unsigned)len << 8);
-            if (AR) {
-                if (__ballot(fin) != 0ull) {
-                    if (fin) {
-                        load_consts<E, UNI>(d, i, c, E::KS, E::K);
-                        reset_lane_sampled<E>(T, d, false, i, reset_seed, (uint64_t)epi, c, s, h);
-                        epi += 1u;
-                        step = 0;
-                    }
-                }
-            } else {
-                frozen |= done;
-            }
-#pragma unroll
-            for (int j = 0; j < E::S; ++j) l_st[b][j][le] = s[j];
-            l_flags[b][le] = fl;
-            __syncthreads();
-        }
-#pragma unroll
-        for (int j = 0; j < E::S; ++j) d.state[j * ld + i] = s[j];
-#pragma unroll
-        for (int j = 0; j < E::H; ++j) d.hidden[j * ld + i] = h[j];
-        d.step[i] = step;
-        d.ep_idx[i] = epi;
-    } else {
-        // ------------------------------------------------------------------------------------------- R wave
-        float a[E::A], ob[E::O];
-        float ret = d.ret[i];
-        float rew = d.rew[i];
-        bool yielded = E::HAS_FINAL ? d.yielded[i] != 0 : false;
-        bool done = d.done[i] != 0, failed = d.failed[i] != 0;
-        EpStat es{0u, d.es_count[i], d.es_retsum[i], d.es_lensum[i]};
-        float alo[E::A], ahi[E::A];
-        E::act_bounds(c, alo, ahi);
-        constexpr unsigned SPB = 4 / E::A;
-        uint4 blk = make_uint4(0, 0, 0, 0);
-        auto gen_action = [&](int t) {
-            uint64_t ta = epoch0 + (uint64_t)t;
-            unsigned sub = (unsigned)(ta % SPB);
-            if (t == 0 || sub == 0) blk = Rng::philox(seed, d.idx0 + (uint32_t)i, RNG_ACT, ta / SPB);
-#pragma unroll
-            for (int j = 0; j < E::A; ++j) {
-                unsigned e = sub * E::A + j;
-                uint32_t bits = e == 0 ? blk.x : e == 1 ? blk.y : e == 2 ? blk.z : blk.w;
-                a[j] = alo[j] + (ahi[j] - alo[j]) * Rng::to_u01(bits);
-            }
-        };
-        gen_action(0);
-#pragma unroll
-        for (int j = 0; j < E::A; ++j) l_act[0][j][le] = a[j];
-        if (REC) E::observe(s, ob);
-        __builtin_amdgcn_s_waitcnt(0x0F70);
-        __syncthreads();
-        for (int t = 0; t < k_steps; ++t) {
-            const int b = t & 1;
-            // while the D wave integrates step t: reward of (s_t, a_t), records of step t, action of step t+1
-            float base = step_reward<E>(T, c, s, a);
-            if (REC) {
-                size_t tb = (size_t)t;
-#pragma unroll
-                for (int j = 0; j < E::O; ++j) d.traj_obs[(tb * E::O + j) * ld + i] = ob[j];
-#pragma unroll
-                for (int j = 0; j < E::A; ++j) d.traj_act[(tb * E::A + j) * ld + i] = a[j];
-            }
-            if (t + 1 < k_steps) {
-                gen_action(t + 1);
-#pragma unroll
-                for (int j = 0; j < E::A; ++j) l_act[b ^ 1][j][le] = a[j];
-            }
-            __syncthreads();
-            unsigned fl = l_flags[b][le];
-#pragma unroll
-            for (int j = 0; j < E::S; ++j) s[j] = l_st[b][j][le];
-            const bool was_frozen = (fl & F_FROZEN) != 0u, fin = (fl & F_FIN) != 0u;
-            const int len = (int)(fl >> 8);
-            if (!was_frozen) {
-                done = (fl & F_DONE) != 0u;
-                failed = (fl & F_FAILED) != 0u;
-                rew = base;
-                if (E::HAS_FINAL) {  // FinalRewTask(always_negative), once per episode (final_reward.py:130-135,165-174)
-                    if (done && !yielded) {
-                        if (failed) rew += -1000.0f;
-                        yielded = true;
-                    }
-                }
-                ret += rew;
-            } else {
-                rew = 0.f;
-            }
-            if (REC) {
-                d.traj_rew[(size_t)t * ld + i] = rew;
-                d.traj_done[(size_t)t * ld + i] = done;
-            }
-            if (__ballot(fin) != 0ull) {
-                if (d.log_episodes) append_episode(d, fin, i, ret, len);
-                if (fin) {
-                    es.count += 1u;
-                    es.retsum += ret;
-                    es.lensum += len;
-                    if (AR) {
-                        ret = 0.f;
-                        yielded = false;
-                    }
-                }
-            }
-            if (REC) E::observe(s, ob);
-        }
-        if (!REC) E::observe(s, ob);
-#pragma unroll
-        for (int j = 0; j < E::O; ++j) d.obs[j * ld + i] = ob[j];
-        d.ret[i] = ret;
-        d.rew[i] = rew;
-        d.done[i] = done;
-        d.failed[i] = failed;
-        if (E::HAS_FINAL) d.yielded[i] = yielded;
-        d.es_count[i] = es.count;
-        d.es_retsum[i] = es.retsum;
-        d.es_lensum[i] = es.lensum;
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------- mixed batches
 // BASELINE config 5: several env families in ONE launch.  Lanes are sorted by type (one segment = one ordinary handle),
 // a workgroup belongs to exactly one segment, so the type switch is uniform per workgroup and every wavefront takes
@@ -812,7 +616,6 @@ struct vs_env {
     bool auto_reset = false;
     uint64_t ar_seed = 0;
     bool uniform = true;
-    int ws_mode = -1;  // fused rollout kernel: -1 auto, 0 plain, 1 wave-specialised (VS_WS env var / vs_set_rollout_variant)
     hipStream_t own_stream = nullptr, stream = nullptr;
     Dev d{};
     int traj_cap = 0;
@@ -932,31 +735,9 @@ static void launch_step(vs_handle h, const float* act, long es, long ds) {
 #undef LS
 }
 
-// wave-specialised variant: pays below two waves per SIMD of the plain kernel (ld <= 2 * 64 * 1024 SIMDs) and needs constants
-// that do not change inside the launch (no live randomizer)
-static bool use_ws(vs_handle h) {
-    if (h->ws_mode == 0) return false;
-    if (h->dr.n > 0) return false;
-    if (h->ws_mode == 1) return true;
-    return h->d.ld <= 131072;
-}
-
 template <class E>
 static void launch_rollout(vs_handle h, int k, uint64_t seed, uint64_t ep, bool rec) {
     bool uni = h->uniform && h->dr.n == 0;
-    if (use_ws(h)) {
-        dim3 g((unsigned)(h->d.ld / WS_ENVS)), b(BLOCK);
-#define LW(U, AR, R) hipLaunchKernelGGL((k_rollout_ws<E, U, AR, R>), g, b, 0, h->stream, h->task, h->d, k, seed, h->ar_seed, ep)
-        if (uni) {
-            if (h->auto_reset) { if (rec) LW(true, true, true); else LW(true, true, false); }
-            else { if (rec) LW(true, false, true); else LW(true, false, false); }
-        } else {
-            if (h->auto_reset) { if (rec) LW(false, true, true); else LW(false, true, false); }
-            else { if (rec) LW(false, false, true); else LW(false, false, false); }
-        }
-#undef LW
-        return;
-    }
     dim3 g = grid_for(h->d.ld), b(BLOCK);
 #define LR(U, AR, R) hipLaunchKernelGGL((k_rollout<E, U, AR, R>), g, b, 0, h->stream, h->task, h->d, k, seed, h->ar_seed, ep)
     if (uni) {
@@ -1058,7 +839,6 @@ int vs_create(int env_type, int64_t n_envs, double dt, int64_t max_steps, int de
     if (!h) return fail(nullptr, VS_ERR_HIP, "vs_create: out of host memory");
     h->type = env_type;
     h->device = device_id;
-    if (const char* ws = getenv("VS_WS")) h->ws_mode = atoi(ws);
     const EnvInfo& ei = ENV_INFO[env_type];
     Task& T = h->task;
     bool defaults = !cfg || cfg->use_defaults;
@@ -1261,12 +1041,6 @@ int vs_step(vs_handle h, const float* actions, int64_t env_stride, int64_t dim_s
     }
     DISPATCH_ENV(h->type, launch_step<E>(h, actions, (long)env_stride, (long)dim_stride));
     HIPCHK(h, hipGetLastError());
-    return VS_OK;
-}
-
-int vs_set_rollout_variant(vs_handle h, int variant) {
-    if (!h || variant < -1 || variant > 1) return VS_ERR_ARG;
-    h->ws_mode = variant;
     return VS_OK;
 }
 

@@ -255,10 +255,6 @@ class VecSimEnv:
             raise ShapeErr(given=actions, expected_match=(self.n_envs, A))
         self._check(self._lib.vs_step(self._h, C.c_void_p(actions.data_ptr()), es, ds), "vs_step")
 
-    def set_rollout_variant(self, variant=-1):
-        """-1 automatic, 0 plain fused kernel, 1 wave-specialised fused kernel (bit-identical results)."""
-        self._check(self._lib.vs_set_rollout_variant(self._h, int(variant)), "vs_set_rollout_variant")
-
     def seek_random(self, step_index=0):
         """Reposition the action stream of step_random (absolute step index, see include/vecsim.h)."""
         self._check(self._lib.vs_seek_random(self._h, int(step_index)), "vs_seek_random")
