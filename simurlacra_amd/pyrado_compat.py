@@ -1,0 +1,24 @@
+"""
+Optional glue for running next to a real Pyrado installation: registers the classes of this package as virtual
+subclasses of Pyrado's ABCs so that `isinstance(inner_env(env), pyrado.environments.sim_base.SimEnv)` checks in Pyrado's
+own wrappers and rollout() (environment_wrappers/domain_randomization.py:56-57, sampling/rollout.py:148) accept them.
+Pyrado does not travel to the GPU box; nothing else in this package imports it.
+"""
+
+
+def register_with_pyrado() -> bool:
+    """Returns True when Pyrado was importable and the registration happened."""
+    try:
+        from pyrado.environment_wrappers.base import EnvWrapper as PyradoEnvWrapper
+        from pyrado.environments.base import Env as PyradoEnv
+        from pyrado.environments.sim_base import SimEnv as PyradoSimEnv
+    except Exception:
+        return False
+    from .envs import VecSimPyEnv
+    from .wrappers import EnvWrapper
+
+    PyradoSimEnv.register(VecSimPyEnv)
+    PyradoEnv.register(VecSimPyEnv)
+    PyradoEnv.register(EnvWrapper)
+    PyradoEnvWrapper.register(EnvWrapper)
+    return True

@@ -234,3 +234,58 @@ def test_shard_layout():
     assert parts == [(0, 3), (3, 3), (6, 2), (8, 2)]
     with pytest.raises(ValueError):
         shard(10, 4, 4)
+
+
+def test_register_with_pyrado_when_the_reference_is_importable():
+    """build container only: with the reference importable (stub harness of SURVEY 8(c)), the env classes of this
+    package satisfy Pyrado's own isinstance checks after register_with_pyrado()"""
+    import sys
+    import types
+
+    ref = "/root/reference/Pyrado"
+    if not os.path.isdir(ref):
+        pytest.skip("reference tree not present (GPU box)")
+    saved = dict(sys.modules)
+    saved_path = list(sys.path)
+    try:
+        np.float = float
+        np.object = object
+
+        def mod(name, **attrs):
+            m = types.ModuleType(name)
+            m.__dict__.update(attrs)
+            sys.modules[name] = m
+            return m
+
+        class _Blank:
+            def __getattr__(self, k):
+                return ""
+
+        class Serializable:
+            @staticmethod
+            def _init(self, locals_):
+                pass
+
+        mod("colorama", Style=_Blank(), Fore=_Blank(), Back=_Blank(), init=lambda **k: None)
+        mod("ipdb", set_trace=lambda *a, **k: None)
+        ias = mod("init_args_serializer", Serializable=Serializable)
+        ias.serializable = mod("init_args_serializer.serializable", Serializable=Serializable)
+        sys.dont_write_bytecode = True
+        sys.path.insert(0, ref)
+        from simurlacra_amd.pyrado_compat import register_with_pyrado
+
+        assert register_with_pyrado()
+        from pyrado.environment_wrappers.utils import inner_env as pyrado_inner_env
+        from pyrado.environments.sim_base import SimEnv as PyradoSimEnv
+
+        env = make("qq-su")
+        w = vs.DomainRandWrapperLive(env, vs.create_default_randomizer(env))
+        assert isinstance(env, PyradoSimEnv) and isinstance(pyrado_inner_env(w), PyradoSimEnv)
+    finally:
+        for k in list(sys.modules):
+            if k not in saved:
+                del sys.modules[k]
+        sys.path[:] = saved_path
+        for attr in ("float", "object"):
+            if attr in np.__dict__:
+                delattr(np, attr)
