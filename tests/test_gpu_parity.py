@@ -610,3 +610,75 @@ def test_mixed_batch_equals_separate_handles(vs, auto_reset):
     exp = ref.step(s0, h0, act.astype(np.float64), ref.nominal_params(sizes[1]).astype(np.float32).astype(np.float64), c0)
     assert_state_close(ref, m.get(L.VS_STATE), exp["state"], ref.nominal_params(sizes[1]))
     mixed.close()
+
+
+def test_full_size_qbb_config4_rank_shard(vs):
+    """BASELINE config 4: QBallBalancerSim, 262 144 envs over 8 GPUs = 32 768 per rank.  One rank's shard on this GPU:
+    polar init on the device, fused rollout with auto-reset, per-env return accumulators (what the RCCL gather reads),
+    shard invariance (global lane index) and a spot check of the last step against the oracle"""
+    L = vs._lib
+    n, rank = 32768, 3
+    env = vs.VecSimEnv("qbb", n, **KW["qbb"])
+    ref = cpu_ref.make_ref("qbb", **KW["qbb"])
+    env.set_index_offset(rank * n)
+    env.set_auto_reset(True, seed=1)
+    env.reset(seed=2)
+    env.step_random(600, seed=3)
+    cnt, rs, ls = env.episode_stats()
+    assert cnt.min() >= 1 and cnt.sum() == (ls > 0).sum() + (cnt - 1).sum()  # every env finished at least one episode (<= 500 steps)
+    assert (ls <= 500 * cnt).all() and np.isfinite(rs).all() and env.error_count() == 0
+    mean_ret = rs.sum(dtype=np.float64) / cnt.sum()
+    assert 0.0 < mean_ret < 500.0
+    # the same global lanes inside a differently cut handle behave identically
+    sub = vs.VecSimEnv("qbb", 4096, **KW["qbb"])
+    sub.set_index_offset(rank * n + 8192)
+    sub.set_auto_reset(True, seed=1)
+    sub.reset(seed=2)
+    sub.step_random(600, seed=3)
+    assert np.array_equal(sub.get(L.VS_STATE), env.get(L.VS_STATE)[8192:8192 + 4096])
+    assert np.array_equal(sub.get(L.VS_EPSTAT_RETSUM), rs[8192:8192 + 4096])
+    # last step against the oracle on 1024 lanes
+    env.set_auto_reset(False)
+    s0 = env.get(L.VS_STATE)[:1024].astype(np.float64)
+    h0 = env.get(L.VS_HIDDEN)[:1024].astype(np.float64)
+    c0 = env.get(L.VS_STEPCOUNT)[:1024]
+    act = f32(np.random.default_rng(0).uniform(-3.5, 3.5, (n, 2)))
+    env.step(dev(act))
+    P = ref.nominal_params(1024).astype(np.float32).astype(np.float64)
+    exp = ref.step(s0, h0, act[:1024].astype(np.float64), P, c0)
+    assert_state_close(ref, env.get(L.VS_STATE)[:1024], exp["state"], P)
+    np.testing.assert_allclose(env.get(L.VS_REW)[:1024], exp["rew"], rtol=RTOL_R, atol=ATOL_R)
+    np.testing.assert_allclose(env.get(L.VS_HIDDEN)[:1024], exp["hidden"], rtol=1e-4, atol=2e-6)
+
+
+def test_full_size_mixed_config5_rank_shard(vs):
+    """BASELINE config 5: 1 M mixed envs over 8 GPUs = 131 072 per rank, a third each of QQube / QCartPole / BallOnBeam,
+    lanes sorted by type, one launch.  Determinism and agreement with stand-alone handles at full per-rank size."""
+    L = vs._lib
+    per = 43520  # 3 * 43 520 = 130 560 <= 131 072, multiple of 256
+    names = ["qq-su", "qcp-su", "bob"]
+
+    def build():
+        ms = [vs.VecSimEnv(nm, per, **KW[nm]) for nm in names]
+        mx = vs.MixedVecSimEnv(ms)
+        for m in ms:
+            m.set_auto_reset(True, seed=7)
+            m.reset(seed=8)
+        return ms, mx
+
+    a_m, a = build()
+    b_m, b = build()
+    a.step_random(120, seed=5)
+    b.step_random(60, seed=5)
+    b.step_random(60, seed=5)  # chunking does not matter: the action stream is keyed by the absolute step index
+    for x, y in zip(a_m, b_m):
+        assert np.array_equal(x.get(L.VS_STATE), y.get(L.VS_STATE))
+        assert np.array_equal(x.get(L.VS_EPSTAT_COUNT), y.get(L.VS_EPSTAT_COUNT))
+        assert x.error_count() == 0
+    solo = vs.VecSimEnv("qcp-su", per, **KW["qcp-su"])
+    solo.set_index_offset(per)
+    solo.set_auto_reset(True, seed=7)
+    solo.reset(seed=8)
+    solo.step_random(120, seed=5)
+    assert np.array_equal(solo.get(L.VS_STATE), a_m[1].get(L.VS_STATE))
+    assert a_m[2].get(L.VS_EPSTAT_COUNT).sum() > per // 2  # ball-on-beam episodes are short under a random policy
