@@ -108,6 +108,7 @@ class EnvRef:
     rew_kind = None
     radial_idcs = ()  # RadiallySymmDesStateTask idcs (empty -> plain DesStateTask)
     final_rew_factor = 0.0  # FinalRewTask(always_negative) malus, 0 -> no FinalRewTask
+    final_state_time_dependent = False  # FinalRewTask(FinalRewMode(state_dependent=True, time_dependent=True))
 
     def __init__(self, dt, max_steps, dtype=np.float64, task_args=None, **flags):
         self.dt = float(dt)
@@ -151,6 +152,9 @@ class EnvRef:
 
     def init_hidden(self, state, params):
         return np.zeros((state.shape[0], self.H), dtype=self.dtype)
+
+    def limit_act(self, act_raw, alo, ahi):
+        return np.clip(act_raw, alo, ahi)  # BoxSpace.project_to (P/spaces/box.py:180-184)
 
     # ---- generic pieces ----
     def c_max(self, params):
@@ -201,7 +205,7 @@ class EnvRef:
         rew = self.step_rew(state, act_raw, params)
         # limit_act -> BoxSpace.project_to (P/spaces/box.py:180-184); NaN raises in the reference -> err flag here
         err = np.isnan(act_raw).any(axis=1)
-        act = np.clip(act_raw, alo, ahi)
+        act = self.limit_act(act_raw, alo, ahi)
         nstate, nhidden = self.dynamics(state, hidden, act, params)
         nstep = curr_step + 1
         err = err | np.isnan(nstate).any(axis=1)
@@ -217,6 +221,15 @@ class EnvRef:
             # FinalRewTask(always_negative).compute_final_rew, once per episode (P/tasks/final_reward.py:130-135,165-174)
             pay = done & ~yielded
             rew = rew + np.where(pay & failed, f(-1.0 * abs(self.final_rew_factor)), f(0.0))
+            nyielded = yielded | pay
+        elif self.final_state_time_dependent:
+            # state- and time-dependent mode (final_reward.py:215-226): -remaining_steps * |step_rew(s', act=0)| on failure;
+            # remaining_steps is the value computed before the step (pysim/base.py:219)
+            pay = done & ~yielded
+            remaining = (int(self.max_steps) - nstep) if self.max_steps != float("inf") else np.zeros_like(nstep)
+            zero_act = np.zeros_like(act_raw)
+            mal = f(-1.0) * remaining.astype(self.dtype) * np.abs(self.step_rew(nstate, zero_act, params))
+            rew = rew + np.where(pay & failed, mal, f(0.0))
             nyielded = yielded | pay
         return dict(state=nstate, hidden=nhidden, obs=self.observe(nstate), rew=rew, done=done, curr_step=nstep,
                     err=err, failed=failed, yielded=nyielded)
@@ -700,8 +713,115 @@ class QBallBalancerRef(EnvRef):
         return np.concatenate([pos, vel], axis=1), nh
 
 
+
+# ------------------------------------------------------------------------------------------------- further pysim families
+class QQubeStabRef(QQubeSwingUpRef):
+    """QQubeStabSim, P/environments/pysim/quanser_qube.py:191-222: same dynamics, other init space and weights"""
+
+    name = "qq-st"
+    Qd = (3.0, 4.0, 2.0, 2.0)
+    Rd = (5e-2,)
+
+    def init_bounds(self, params):
+        n = params.shape[0]
+        lo = np.tile(np.array([-5.0 / 180 * PI, 175.0 / 180 * PI, 0, 0], dtype=self.dtype), (n, 1))
+        hi = np.tile(np.array([5.0 / 180 * PI, 185.0 / 180 * PI, 0, 0], dtype=self.dtype), (n, 1))
+        return lo, hi
+
+
+class QCartPoleStabRef(QCartPoleSwingUpRef):
+    """QCartPoleStabSim, P/environments/pysim/quanser_cartpole.py:441-504 (ctor defaults long=True, simple_dynamics=True)"""
+
+    name = "qcp-st"
+    Qd = (5e-0, 1e1, 1e-2, 1e-2)
+    Rd = (1e-3,)
+    rew_kind = REW_QUADR
+    final_state_time_dependent = True
+    STAB_THOLD = 15 / 180.0 * PI
+    MAX_INIT_TH_OFFSET = 8 / 180.0 * PI
+
+    def __init__(self, dt, max_steps, dtype=np.float64, task_args=None, **flags):
+        flags.setdefault("long", True)
+        flags.setdefault("simple_dynamics", True)
+        super().__init__(dt, max_steps, dtype=dtype, task_args=task_args, **flags)
+
+    @classmethod
+    def nominal_params(cls, n=1, dtype=np.float64, long=True, mass=None, **flags):
+        return super().nominal_params(n, dtype, long=long, mass=mass)
+
+    def bounds(self, params):
+        f = self._f
+        l_rail = self.p(params, "rail_length")
+        one = np.ones_like(l_rail)
+        slo = np.stack([-l_rail / f(2.0) + f(self.X_BUFFER), one * f(PI - self.STAB_THOLD), -l_rail, one * f(-2 * PI)], axis=1)
+        shi = np.stack([+l_rail / f(2.0) - f(self.X_BUFFER), one * f(PI + self.STAB_THOLD), +l_rail, one * f(+2 * PI)], axis=1)
+        amax = np.full((params.shape[0], 1), self.MAX_ACT, dtype=self.dtype)
+        return slo, shi, -amax, amax
+
+    def init_bounds(self, params):
+        n = params.shape[0]
+        hi = np.tile(np.array([+0.02, PI + self.MAX_INIT_TH_OFFSET, +0.02, +5 / 180 * PI], dtype=self.dtype), (n, 1))
+        lo = np.tile(np.array([-0.02, PI - self.MAX_INIT_TH_OFFSET, -0.02, -5 / 180 * PI], dtype=self.dtype), (n, 1))
+        return lo, hi
+
+
+class PendulumRef(EnvRef):
+    """PendulumSim, P/environments/pysim/pendulum.py:43-117"""
+
+    name = "pend"
+    S, A, O, H, I = 2, 1, 3, 0, 2
+    param_names = ("gravity_const", "pole_mass", "pole_length", "pole_damping", "torque_thold")
+    nominal = (9.81, 1.0, 1.0, 0.05, 3.5)
+    state_des = np.array([PI, 0.0])
+    Qd = (1e-0, 1e-3)
+    Rd = (1e-2,)
+    rew_kind = REW_EXP
+    radial_idcs = (1,)  # idcs=[1] in the reference: the modulo hits theta_dot (pendulum.py:87)
+
+    def bounds(self, params):
+        n = params.shape[0]
+        smax = np.tile(np.array([4 * PI, 4 * PI], dtype=self.dtype), (n, 1))
+        amax = self.p(params, "torque_thold")[:, None].copy()
+        return -smax, smax, -amax, amax
+
+    def init_bounds(self, params):
+        n = params.shape[0]
+        fixed = np.tile(np.asarray(self.flags.get("init_state", np.zeros(2)), dtype=self.dtype), (n, 1))
+        return fixed, fixed.copy()  # SingularStateSpace
+
+    def dynamics(self, state, hidden, act, params):
+        f = self._f
+        g, m, l, dmp = (self.p(params, k) for k in ("gravity_const", "pole_mass", "pole_length", "pole_damping"))  # noqa: E741
+        th, th_dot = state[:, 0], state[:, 1]
+        th_ddot = (act[:, 0] - m * g * l / f(2.0) * np.sin(th) - dmp * th_dot) / (m * l ** 2 / f(3.0))
+        v = th_dot + th_ddot * f(self.dt)  # symplectic Euler
+        p = th + v * f(self.dt)
+        return np.stack([p, v], axis=1), hidden
+
+    def observe(self, state):
+        return np.stack([np.sin(state[:, 0]), np.cos(state[:, 0]), state[:, 1]], axis=1)
+
+
+class BallOnBeamDiscRef(BallOnBeamRef):
+    """BallOnBeamDiscSim, P/environments/pysim/ball_on_beam.py:139-161: actions are snapped to {-max, 0, +max}
+    (DiscreteSpace.project_to, P/spaces/discrete.py:104-131)"""
+
+    name = "bob-d"
+
+    def limit_act(self, act_raw, alo, ahi):
+        eles = np.stack([alo[:, 0], (alo[:, 0] + ahi[:, 0]) * self._f(0.5), ahi[:, 0]], axis=1)  # linspace(min, max, 3)
+        a = act_raw[:, 0:1]
+        close = np.isclose(eles, a).any(axis=1)  # contains(): approximately equal to one of the elements
+        idx = np.argmin(np.abs(a - eles), axis=1)
+        snapped = eles[np.arange(len(idx)), idx]
+        out = np.where(close, a[:, 0], snapped)
+        out = np.where(np.isnan(a[:, 0]), a[:, 0], out)
+        return out[:, None]
+
+
 ENV_REFS = OrderedDict((c.name, c) for c in (OneMassOscillatorRef, BallOnBeamRef, QQubeSwingUpRef,
-                                              QCartPoleSwingUpRef, QBallBalancerRef))
+                                              QCartPoleSwingUpRef, QBallBalancerRef, QQubeStabRef, QCartPoleStabRef,
+                                              PendulumRef, BallOnBeamDiscRef))
 
 
 def make_ref(name, dt, max_steps, dtype=np.float64, task_args=None, **flags):

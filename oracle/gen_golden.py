@@ -54,11 +54,12 @@ import torch  # noqa: E402
 
 import pyrado  # noqa: E402
 from pyrado.domain_randomization.default_randomizers import create_default_randomizer  # noqa: E402
-from pyrado.environments.pysim.ball_on_beam import BallOnBeamSim  # noqa: E402
+from pyrado.environments.pysim.ball_on_beam import BallOnBeamDiscSim, BallOnBeamSim  # noqa: E402
 from pyrado.environments.pysim.one_mass_oscillator import OneMassOscillatorSim  # noqa: E402
+from pyrado.environments.pysim.pendulum import PendulumSim  # noqa: E402
 from pyrado.environments.pysim.quanser_ball_balancer import QBallBalancerSim  # noqa: E402
-from pyrado.environments.pysim.quanser_cartpole import QCartPoleSwingUpSim  # noqa: E402
-from pyrado.environments.pysim.quanser_qube import QQubeSwingUpSim  # noqa: E402
+from pyrado.environments.pysim.quanser_cartpole import QCartPoleStabSim, QCartPoleSwingUpSim  # noqa: E402
+from pyrado.environments.pysim.quanser_qube import QQubeStabSim, QQubeSwingUpSim  # noqa: E402
 
 # env kwargs = Pyrado/tests/conftest.py:160-193
 ENVS = {
@@ -67,12 +68,17 @@ ENVS = {
     "qq-su": (QQubeSwingUpSim, dict(dt=0.004, max_steps=4000)),
     "qcp-su": (QCartPoleSwingUpSim, dict(dt=0.002, max_steps=8000)),
     "qbb": (QBallBalancerSim, dict(dt=0.01, max_steps=500)),
+    # the remaining pysim families, kwargs = Pyrado/tests/conftest.py:164-189
+    "qq-st": (QQubeStabSim, dict(dt=0.01, max_steps=500)),
+    "qcp-st": (QCartPoleStabSim, dict(dt=0.01, max_steps=300)),
+    "pend": (PendulumSim, dict(dt=0.02, max_steps=400, init_state=np.array([0.1, 0.2]))),
+    "bob-d": (BallOnBeamDiscSim, dict(dt=0.01, max_steps=500)),
 }
-HIDDEN = {"omo": 0, "bob": 0, "qq-su": 0, "qcp-su": 1, "qbb": 2}
+HIDDEN = {"omo": 0, "bob": 0, "qq-su": 0, "qcp-su": 1, "qbb": 2, "qq-st": 0, "qcp-st": 1, "pend": 0, "bob-d": 0}
 
 
 def get_hidden(name, env):
-    if name == "qcp-su":
+    if name in ("qcp-su", "qcp-st"):
         return np.array([float(env._th_ddot)])
     if name == "qbb":
         return np.array(env.plate_angs, dtype=np.float64).copy()
@@ -80,7 +86,7 @@ def get_hidden(name, env):
 
 
 def set_hidden(name, env, h):
-    if name == "qcp-su":
+    if name in ("qcp-su", "qcp-st"):
         env._th_ddot = float(h[0])
     elif name == "qbb":
         env.plate_angs = np.array(h, dtype=np.float64).copy()
@@ -105,7 +111,7 @@ def draw_params(name, env, rng, randomizer, mode):
         randomizer.randomize(num_samples=1)
         for k, v in randomizer.get_params(fmt="dict", dtype="numpy").items():
             dp[k] = float(v)
-    if mode == 2 and name in ("qq-su", "qcp-su"):
+    if mode == 2 and name in ("qq-su", "qcp-su", "qq-st", "qcp-st"):
         dp["voltage_thold_neg"] = float(np.float32(-rng.uniform(0.05, 0.6)))
         dp["voltage_thold_pos"] = float(np.float32(rng.uniform(0.05, 0.6)))
     return dp
@@ -203,7 +209,7 @@ def gen_traj(name, n_traj, t_max, seed, extra_after_done=3):
         dp = draw_params(name, env, rng, randomizer, 0 if i < n_traj // 2 else 1)
         env.reset(domain_param=dp)  # spaces for these params
         init = env.init_space.sample_uniform()
-        if name in ("omo", "bob") and i % 2 == 1:
+        if name in ("omo", "bob", "bob-d") and i % 2 == 1:
             # start close to a bound so the episode fails early (covers failure malus / done)
             init = np.array(init)
             init[0] = 0.97 * env.state_space.bound_up[0]
@@ -268,7 +274,7 @@ def gen_reset(name, m, seed):
         rec["obs"].append(np.array(obs, dtype=np.float64))
         for k in ("state_lo", "state_hi", "act_lo", "act_hi", "c_max"):
             rec[k].append(info[k])
-        if name == "bob":
+        if name in ("bob", "bob-d"):
             sp = env.init_space.subspace(0)
             sp1 = env.init_space.subspace(1)
             rec["init_lo"].append(np.concatenate([sp.bound_lo, sp1.bound_lo]))
@@ -331,16 +337,22 @@ def gen_ik(seed=3):
 
 def main():
     os.makedirs(OUT, exist_ok=True)
-    m_step = {"omo": 256, "bob": 256, "qq-su": 256, "qcp-su": 256, "qbb": 128}
-    t_traj = {"omo": 300, "bob": 200, "qq-su": 200, "qcp-su": 200, "qbb": 150}
+    m_step = {"omo": 256, "bob": 256, "qq-su": 256, "qcp-su": 256, "qbb": 128, "qq-st": 192, "qcp-st": 192, "pend": 192,
+              "bob-d": 192}
+    t_traj = {"omo": 300, "bob": 200, "qq-su": 200, "qcp-su": 200, "qbb": 150, "qq-st": 150, "qcp-st": 150, "pend": 200,
+              "bob-d": 150}
+    force = "--force" in sys.argv
     for i, name in enumerate(ENVS):
         tag = name.replace("-", "_")
+        if os.path.exists(os.path.join(OUT, f"step_{tag}.npz")) and not force:
+            continue  # fixtures are committed; only new families are generated (pass --force to redo everything)
         np.savez_compressed(os.path.join(OUT, f"step_{tag}.npz"), **gen_step_cases(name, m_step[name], 100 + i))
         np.savez_compressed(os.path.join(OUT, f"traj_{tag}.npz"), **gen_traj(name, 8, t_traj[name], 200 + i))
         np.savez_compressed(os.path.join(OUT, f"reset_{tag}.npz"), **gen_reset(name, 16, 300 + i))
         print("wrote", name, flush=True)
-    np.savez_compressed(os.path.join(OUT, "cfg1_omo_500.npz"), **gen_cfg1())
-    np.savez_compressed(os.path.join(OUT, "qbb_ik.npz"), **gen_ik())
+    if force or not os.path.exists(os.path.join(OUT, "cfg1_omo_500.npz")):
+        np.savez_compressed(os.path.join(OUT, "cfg1_omo_500.npz"), **gen_cfg1())
+        np.savez_compressed(os.path.join(OUT, "qbb_ik.npz"), **gen_ik())
     with open(os.path.join(OUT, "randomizers.json"), "w") as fh:
         json.dump(gen_randomizer_tables(), fh, indent=1, sort_keys=True)
     # seed KAT straight from the reference function (table also in Pyrado/tests/test_set_seed.py:35-54)

@@ -10,9 +10,11 @@ import pytest
 
 from oracle import cpu_ref
 
-ENVS = ["omo", "bob", "qq-su", "qcp-su", "qbb"]
+ENVS = ["omo", "bob", "qq-su", "qcp-su", "qbb", "qq-st", "qcp-st", "pend", "bob-d"]
 KW = {"omo": dict(dt=0.02, max_steps=300), "bob": dict(dt=0.01, max_steps=500), "qq-su": dict(dt=0.004, max_steps=4000),
-      "qcp-su": dict(dt=0.002, max_steps=8000), "qbb": dict(dt=0.01, max_steps=500)}
+      "qcp-su": dict(dt=0.002, max_steps=8000), "qbb": dict(dt=0.01, max_steps=500),
+      "qq-st": dict(dt=0.01, max_steps=500), "qcp-st": dict(dt=0.01, max_steps=300),
+      "pend": dict(dt=0.02, max_steps=400, init_state=np.array([0.1, 0.2])), "bob-d": dict(dt=0.01, max_steps=500)}
 # fp64 restatement vs fp64 reference: op-for-op, only BLAS/LAPACK summation order may differ
 RTOL, ATOL = 1e-11, 1e-13
 
@@ -66,7 +68,7 @@ def test_trajectories(golden_dir, name):
             np.testing.assert_allclose(out["rew"][0], g["rew"][i, t], rtol=1e-10, atol=1e-300)
             assert bool(out["done"][0]) == bool(g["done"][i, t])
             saw_done |= bool(g["done"][i, t])
-    if name in ("omo", "bob"):
+    if name in ("omo", "bob", "bob-d", "qcp-st"):
         assert saw_done
     # ... and free-running (closed loop in the oracle) over a short horizon
     state, hidden = r["state"], r["hidden"]
@@ -90,7 +92,7 @@ def test_reset_cases(golden_dir, name):
         np.testing.assert_allclose(r["obs"][0], g["obs"][i], rtol=RTOL, atol=ATOL)
         if ref.H:
             np.testing.assert_allclose(r["hidden"][0], g["hidden"][i], rtol=0, atol=2e-6)
-    if name == "bob":
+    if name in ("bob", "bob-d"):
         lo0, hi0 = ref.init_bounds(g["params"], box=0)
         lo1, hi1 = ref.init_bounds(g["params"], box=1)
         np.testing.assert_allclose(np.concatenate([lo0, lo1], axis=1), g["init_lo"], rtol=1e-14)
@@ -174,5 +176,7 @@ def test_nominal_params_match_reference(golden_dir):
     for name, cls in cpu_ref.ENV_REFS.items():
         nom = tab[name]["nominal"]
         assert list(nom.keys()) == sorted(cls.param_names)  # json sort_keys
-        for k, v in zip(cls.param_names, cls.nominal):
+        # get_nominal_domain_param() is a classmethod with long=False as default, also for QCartPoleStabSim
+        nominal = cls.nominal_params(1, long=False)[0] if name == "qcp-st" else cls.nominal_params(1)[0]
+        for k, v in zip(cls.param_names, nominal):
             assert nom[k] == pytest.approx(v, rel=1e-15, abs=0)
