@@ -40,7 +40,12 @@ enum vs_env_type {
     VS_ENV_QQ_SU = 2,  /* "qq-su"  QQubeSwingUpSim       P/environments/pysim/quanser_qube.py:41-188 */
     VS_ENV_QCP_SU = 3, /* "qcp-su" QCartPoleSwingUpSim   P/environments/pysim/quanser_cartpole.py:45-230,507-587 */
     VS_ENV_QBB = 4,    /* "qbb"    QBallBalancerSim      P/environments/pysim/quanser_ball_balancer.py:49-337 */
-    VS_ENV_COUNT = 5
+    /* the remaining pysim families, sharing the kernels above */
+    VS_ENV_QQ_ST = 5,  /* "qq-st"  QQubeStabSim          P/environments/pysim/quanser_qube.py:191-222 */
+    VS_ENV_QCP_ST = 6, /* "qcp-st" QCartPoleStabSim      P/environments/pysim/quanser_cartpole.py:441-504 (flags default to long + simple) */
+    VS_ENV_PEND = 7,   /* "pend"   PendulumSim           P/environments/pysim/pendulum.py:43-117 */
+    VS_ENV_BOB_D = 8,  /* "bob-d"  BallOnBeamDiscSim     P/environments/pysim/ball_on_beam.py:139-161 */
+    VS_ENV_COUNT = 9
 };
 
 /* buffers addressable through vs_get / vs_copy_to_host / vs_copy_from_host */
@@ -84,6 +89,7 @@ typedef struct vs_task_cfg {
     float state_des[8];   /* task_args['state_des'] */
     float q_diag[8];      /* diag(task_args['Q']) */
     float r_diag[2];      /* diag(task_args['R']) */
+    float init_state[8];  /* pend: the fixed initial state of its SingularStateSpace (ctor arg init_state) */
 } vs_task_cfg;
 
 /* One randomised domain parameter: DomainParam.sample = distr.sample -> clamp(clip_lo, clip_up)

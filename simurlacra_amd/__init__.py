@@ -10,11 +10,12 @@ from . import _lib  # noqa: F401
 from .domain_randomization import (DomainParam, DomainRandomizer, NormalDomainParam, UniformDomainParam,  # noqa: F401
                                    create_conservative_randomizer, create_default_randomizer,
                                    create_zero_var_randomizer)
-from .envs import (ENV_CLASSES, BallOnBeamSim, OneMassOscillatorSim, QBallBalancerSim, QCartPoleSwingUpSim,  # noqa: F401
-                   QQubeSwingUpSim, SimEnv, VecSimPyEnv)
+from .envs import (ENV_CLASSES, BallOnBeamDiscSim, BallOnBeamSim, OneMassOscillatorSim, PendulumSim,  # noqa: F401
+                   QBallBalancerSim, QCartPoleStabSim, QCartPoleSwingUpSim, QQubeStabSim, QQubeSwingUpSim, SimEnv,
+                   VecSimPyEnv)
 from .exceptions import KeyErr, ShapeErr, TypeErr, ValueErr  # noqa: F401
 from .seeding import derive_seed, get_base_seed, set_seed  # noqa: F401
-from .spaces import BoxSpace, CompoundSpace, EnvSpec, Polar2DPosVelSpace  # noqa: F401
+from .spaces import BoxSpace, CompoundSpace, DiscreteSpace, EnvSpec, Polar2DPosVelSpace, SingularStateSpace  # noqa: F401
 from .vec_env import MixedVecSimEnv, VecSimEnv, env_dims, nominal_params, param_names  # noqa: F401
 from .wrappers import DomainRandWrapper, DomainRandWrapperLive, EnvWrapper, all_envs, inner_env, typed_env  # noqa: F401
 

@@ -6,7 +6,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("VS_LIB_PATH") or os.path.join(_HERE, "csrc", "libvecsim.so")  # override: diagnostic builds
 
 VS_OK, VS_ERR_ARG, VS_ERR_HIP, VS_ERR_STATE, VS_ERR_NAN = 0, -1, -2, -3, -4
-ENV_TYPES = {"omo": 0, "bob": 1, "qq-su": 2, "qcp-su": 3, "qbb": 4}
+ENV_TYPES = {"omo": 0, "bob": 1, "qq-su": 2, "qcp-su": 3, "qbb": 4, "qq-st": 5, "qcp-st": 6, "pend": 7, "bob-d": 8}
 (VS_STATE, VS_OBS, VS_REW, VS_DONE, VS_HIDDEN, VS_STEPCOUNT, VS_ERRFLAG, VS_RETURNS, VS_PARAMS, VS_CONSTS,
  VS_EP_RETURNS, VS_EP_LENGTHS, VS_EP_ENVIDX, VS_EP_COUNT, VS_TRAJ_OBS, VS_TRAJ_ACT, VS_TRAJ_REW, VS_TRAJ_DONE,
  VS_FAILED, VS_EPSTAT_COUNT, VS_EPSTAT_RETSUM, VS_EPSTAT_LENSUM) = range(22)
@@ -16,7 +16,8 @@ VS_DP_NORMAL, VS_DP_UNIFORM = 0, 1
 
 class TaskCfg(C.Structure):
     _fields_ = [("use_defaults", C.c_int32), ("flags", C.c_int32), ("wild_init", C.c_int32), ("reserved", C.c_int32),
-                ("state_des", C.c_float * 8), ("q_diag", C.c_float * 8), ("r_diag", C.c_float * 2)]
+                ("state_des", C.c_float * 8), ("q_diag", C.c_float * 8), ("r_diag", C.c_float * 2),
+                ("init_state", C.c_float * 8)]
 
 
 class DpSpec(C.Structure):

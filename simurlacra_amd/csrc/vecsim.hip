@@ -95,11 +95,8 @@ __device__ __forceinline__ StepOut step_one(const Task& T, const float* c, float
     E::act_bounds(c, alo, ahi);
     o.err = false;
 #pragma unroll
-    for (int j = 0; j < E::A; ++j) {
-        o.err |= isnan(a_raw[j]);
-        a[j] = fminf(fmaxf(a_raw[j], alo[j]), ahi[j]);  // limit_act -> BoxSpace.project_to (box.py:180-184)
-        if (isnan(a_raw[j])) a[j] = a_raw[j];           // np.clip propagates NaN (fminf/fmaxf would drop it)
-    }
+    for (int j = 0; j < E::A; ++j) o.err |= isnan(a_raw[j]);
+    E::limit_act(c, alo, ahi, a_raw, a);  // Env.limit_act -> act_space.project_to
 #ifdef VS_ABLATE_DYNAMICS
     s[0] += a[0] * 1e-6f;
 #else
@@ -117,10 +114,22 @@ __device__ __forceinline__ StepOut step_one(const Task& T, const float* c, float
         o.failed |= E::SYMMETRIC_BOX ? (fabsf(s[j]) > shi[j]) : ((s[j] < slo[j]) | (s[j] > shi[j]));
     }
     o.done = o.failed | (step >= T.max_steps);
-    if (E::HAS_FINAL) {
-        // FinalRewTask(always_negative): -factor on failure, paid once per episode (final_reward.py:130-135,165-174)
+    if (E::FINAL != FINAL_NONE) {
+        // FinalRewTask.compute_final_rew, paid once per episode (P/tasks/final_reward.py:130-135)
         if (o.done && !yielded) {
-            if (o.failed) o.rew += -1000.0f;
+            if (o.failed) {
+                if (E::FINAL == FINAL_CONST_MALUS) {
+                    o.rew += -1000.0f;  // always_negative, factor 1e3 (:165-174)
+                } else {
+                    // state- and time-dependent (:215-226): -remaining_steps * |step_rew(s', act = 0)|, remaining_steps as
+                    // computed before the step (pysim/base.py:219); 0 for max_steps = inf
+                    float zero[E::A];
+#pragma unroll
+                    for (int j = 0; j < E::A; ++j) zero[j] = 0.f;
+                    float remaining = T.max_steps == INT_MAX ? 0.f : (float)(T.max_steps - step);
+                    o.rew += -1.0f * remaining * fabsf(step_reward<E>(T, c, s, zero));
+                }
+            }
             yielded = true;
         }
     }
@@ -243,7 +252,7 @@ __device__ __forceinline__ void step_body(const Task& T, const Dev& d, const flo
 #pragma unroll
     for (int j = 0; j < E::A; ++j) a[j] = valid ? act[(size_t)i * env_stride + (size_t)j * dim_stride] : 0.f;
     int step = d.step[i];
-    bool yielded = E::HAS_FINAL ? d.yielded[i] != 0 : false;
+    bool yielded = E::FINAL != FINAL_NONE ? d.yielded[i] != 0 : false;
 
     StepOut o = step_one<E>(T, c, s, h, a, step, yielded, nullptr);
 
@@ -278,7 +287,7 @@ __device__ __forceinline__ void step_body(const Task& T, const Dev& d, const flo
     for (int j = 0; j < E::O; ++j) d.obs[j * ld + i] = ob[j];
     d.step[i] = step;
     d.ret[i] = ret;
-    if (E::HAS_FINAL) d.yielded[i] = yielded;
+    if (E::FINAL != FINAL_NONE) d.yielded[i] = yielded;
 }
 
 template <class E, bool UNI, bool AR>
@@ -308,7 +317,7 @@ __device__ __forceinline__ void rollout_body(const Task& T, const Dev& d, int k_
     for (int j = 0; j < E::H; ++j) h[j] = d.hidden[j * ld + i];
     int step = d.step[i];
     float ret = d.ret[i];
-    bool yielded = E::HAS_FINAL ? d.yielded[i] != 0 : false;
+    bool yielded = E::FINAL != FINAL_NONE ? d.yielded[i] != 0 : false;
     bool frozen = !AR && d.done[i] != 0;
     float rew = d.rew[i];
     bool done = d.done[i] != 0, failed = d.failed[i] != 0;
@@ -335,7 +344,7 @@ __device__ __forceinline__ void rollout_body(const Task& T, const Dev& d, int k_
         for (int j = 0; j < E::A; ++j) {
             unsigned e = sub * E::A + j;  // wave-uniform element index
             uint32_t bits = e == 0 ? blk.x : e == 1 ? blk.y : e == 2 ? blk.z : blk.w;
-            a[j] = alo[j] + (ahi[j] - alo[j]) * Rng::to_u01(bits);  // act_space.sample_uniform()
+            a[j] = E::sample_action(c, alo[j], ahi[j], Rng::to_u01(bits), j);  // act_space.sample_uniform()
         }
         if (REC) {
             size_t tb = (size_t)t;
@@ -389,7 +398,7 @@ __device__ __forceinline__ void rollout_body(const Task& T, const Dev& d, int k_
     d.rew[i] = rew;
     d.done[i] = done;
     d.failed[i] = failed;
-    if (E::HAS_FINAL) d.yielded[i] = yielded;
+    if (E::FINAL != FINAL_NONE) d.yielded[i] = yielded;
     d.ep_idx[i] = es.epi;
     d.es_count[i] = es.count;
     d.es_retsum[i] = es.retsum;
@@ -427,7 +436,11 @@ struct Segs {
         case VS_ENV_BOB: { using E = Bob; __VA_ARGS__; } break;     \
         case VS_ENV_QQ_SU: { using E = QQ; __VA_ARGS__; } break;    \
         case VS_ENV_QCP_SU: { using E = Qcp; __VA_ARGS__; } break;  \
-        default: { using E = Qbb; __VA_ARGS__; } break;             \
+        case VS_ENV_QBB: { using E = Qbb; __VA_ARGS__; } break;     \
+        case VS_ENV_QQ_ST: { using E = QQSt; __VA_ARGS__; } break;  \
+        case VS_ENV_QCP_ST: { using E = QcpSt; __VA_ARGS__; } break;\
+        case VS_ENV_PEND: { using E = Pend; __VA_ARGS__; } break;   \
+        default: { using E = BobD; __VA_ARGS__; } break;            \
     }
 
 template <bool AR, bool REC>
@@ -604,7 +617,29 @@ static const EnvInfo ENV_INFO[VS_ENV_COUNT] = {
       "offset_th_x", "offset_th_y"},
      {9.81f, 0.003f, 0.019625f, 0.275f, 0.0254f, 70.0f, 0.9f, 5.2822e-5f, 4.6063e-7f, 0.0077f, 2.6f, 0.69f, 0.015f,
       0.05f, 0.28f, -0.10f, 0.28f, -0.074f, 0.0f, 0.0f},  // quanser_ball_balancer.py:141-143,171-202
-     {0, 0, 0, 0, 0, 0, 0, 0}, {1e0f, 1e0f, 5e3f, 5e3f, 1e-2f, 1e-2f, 5e-1f, 5e-1f}, {1e-2f, 1e-2f}}};  // :119-129
+     {0, 0, 0, 0, 0, 0, 0, 0}, {1e0f, 1e0f, 5e3f, 5e3f, 1e-2f, 1e-2f, 5e-1f, 5e-1f}, {1e-2f, 1e-2f}},  // :119-129
+    // ---- the remaining pysim families ----
+    {"qq-st", QQSt::S, QQSt::A, QQSt::O, QQSt::P, QQSt::H, QQSt::I, QQSt::K,
+     {"gravity_const", "motor_resistance", "motor_back_emf", "mass_rot_pole", "length_rot_pole", "damping_rot_pole",
+      "mass_pend_pole", "length_pend_pole", "damping_pend_pole", "voltage_thold_neg", "voltage_thold_pos"},
+     {9.81f, 8.4f, 0.042f, 0.095f, 0.085f, 5e-6f, 0.024f, 0.129f, 1e-6f, 0.0f, 0.0f},
+     {0.0f, PI_F, 0.0f, 0.0f}, {3.0f, 4.0f, 2.0f, 2.0f}, {5e-2f}},  // quanser_qube.py:215-222
+    {"qcp-st", QcpSt::S, QcpSt::A, QcpSt::O, QcpSt::P, QcpSt::H, QcpSt::I, QcpSt::K,
+     {"gravity_const", "cart_mass", "rail_length", "motor_efficiency", "gear_efficiency", "gear_ratio",
+      "motor_inertia", "pinion_radius", "motor_resistance", "motor_back_emf", "pole_damping", "combined_damping",
+      "pole_mass", "pole_length", "cart_friction_coeff", "voltage_thold_neg", "voltage_thold_pos"},
+     {9.81f, 0.58f, 0.814f, 0.9f, 0.9f, 3.71f, 3.9e-7f, 6.35e-3f, 2.6f, 7.67e-3f, 0.0024f, 5.4f, 0.127f,
+      0.3365f / 2, 0.02f, 0.0f, 0.0f},
+     {0.0f, PI_F, 0.0f, 0.0f}, {5e-0f, 1e1f, 1e-2f, 1e-2f}, {1e-3f}},  // quanser_cartpole.py:494-504
+    {"pend", Pend::S, Pend::A, Pend::O, Pend::P, Pend::H, Pend::I, Pend::K,
+     {"gravity_const", "pole_mass", "pole_length", "pole_damping", "torque_thold"},
+     {9.81f, 1.0f, 1.0f, 0.05f, 3.5f},  // pendulum.py:94-101
+     {PI_F, 0.0f}, {1e-0f, 1e-3f}, {1e-2f}},  // :82-87
+    {"bob-d", BobD::S, BobD::A, BobD::O, BobD::P, BobD::H, BobD::I, BobD::K,
+     {"gravity_const", "ball_mass", "ball_radius", "beam_mass", "beam_length", "beam_thickness", "friction_coeff",
+      "ang_offset"},
+     {9.81f, 0.5f, 0.1f, 3.0f, 2.0f, 0.1f, 0.05f, 0.0f},
+     {0, 0, 0, 0}, {1e5f, 1e3f, 1e3f, 1e2f}, {1.0f}}};
 
 struct vs_env {
     int type = 0;
@@ -654,6 +689,10 @@ static int fail(vs_handle h, int code, const char* what, hipError_t e = hipSucce
         case VS_ENV_QQ_SU: { using E = QQ; __VA_ARGS__; } break;   \
         case VS_ENV_QCP_SU: { using E = Qcp; __VA_ARGS__; } break; \
         case VS_ENV_QBB: { using E = Qbb; __VA_ARGS__; } break;    \
+        case VS_ENV_QQ_ST: { using E = QQSt; __VA_ARGS__; } break; \
+        case VS_ENV_QCP_ST: { using E = QcpSt; __VA_ARGS__; } break; \
+        case VS_ENV_PEND: { using E = Pend; __VA_ARGS__; } break;  \
+        case VS_ENV_BOB_D: { using E = BobD; __VA_ARGS__; } break; \
         default: break;                                          \
     }
 
@@ -790,7 +829,7 @@ static int mixed_upload(vs_mixed* m, const float* const* acts, const int64_t* en
 
 extern "C" {
 
-int vs_version(void) { return 100; }
+int vs_version(void) { return 110; }
 
 int vs_env_dims(int t, int* S, int* A, int* O, int* P, int* H, int* I, int* K) {
     if (t < 0 || t >= VS_ENV_COUNT) return VS_ERR_ARG;
@@ -815,7 +854,7 @@ const char* vs_param_name(int t, int i) {
 int vs_nominal_params(int t, int flags, float* out) {
     if (t < 0 || t >= VS_ENV_COUNT || !out) return VS_ERR_ARG;
     for (int k = 0; k < ENV_INFO[t].P; ++k) out[k] = ENV_INFO[t].nominal[k];
-    if (t == VS_ENV_QCP_SU && (flags & VS_FLAG_LONG_POLE)) {  // get_nominal_domain_param(long=True), :113-118
+    if ((t == VS_ENV_QCP_SU || t == VS_ENV_QCP_ST) && (flags & VS_FLAG_LONG_POLE)) {  // get_nominal_domain_param(long=True), :113-118
         out[12] = 0.23f;
         out[13] = 0.641f / 2;
     }
@@ -849,8 +888,10 @@ int vs_create(int env_type, int64_t n_envs, double dt, int64_t max_steps, int de
     for (int j = 0; j < MAXA; ++j) T.rd[j] = defaults ? ei.rd[j] : cfg->r_diag[j];
     T.dt = (float)dt;
     T.max_steps = (max_steps <= 0 || max_steps >= INT_MAX) ? INT_MAX : (int)max_steps;
-    T.flags = cfg ? cfg->flags : 0;
+    // without a cfg the ctor defaults of the reference apply: QCartPoleStabSim(long=True, simple_dynamics=True)
+    T.flags = cfg ? cfg->flags : (env_type == VS_ENV_QCP_ST ? (VS_FLAG_LONG_POLE | VS_FLAG_SIMPLE_DYNAMICS) : 0);
     T.wild_init = cfg ? cfg->wild_init : 0;
+    for (int j = 0; j < MAXS; ++j) T.init_fixed[j] = cfg ? cfg->init_state[j] : 0.f;
     int rc = VS_OK;
 #define CK(x) do { rc = (x); if (rc != VS_OK) { g_create_err = h->err; vs_destroy(h); return rc; } } while (0)
 #define HK(x) do { hipError_t e2 = (x); if (e2 != hipSuccess) { fail(nullptr, VS_ERR_HIP, #x, e2); vs_destroy(h); return VS_ERR_HIP; } } while (0)

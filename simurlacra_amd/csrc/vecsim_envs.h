@@ -34,6 +34,7 @@ struct Task {
     int max_steps;  // INT_MAX == pyrado.inf
     int flags;      // VS_FLAG_*
     int wild_init;  // qcp only
+    float init_fixed[MAXS];  // SingularStateSpace (pend): the fixed initial state
 };
 
 // ------------------------------------------------------------------------------------------------- small helpers
@@ -151,13 +152,30 @@ struct Rng {
 };
 enum RngPurpose { RNG_ACT = 1, RNG_INIT = 2, RNG_PARAM = 3 };
 
+// defaults shared by the env structs (static members are inherited)
+enum FinalKind { FINAL_NONE = 0, FINAL_CONST_MALUS = 1, FINAL_STATE_TIME = 2 };
+template <int A_>
+struct EnvDefaults {
+    static constexpr bool SYMMETRIC_BOX = true;  // state box lo == -hi
+    static constexpr int FINAL = FINAL_NONE;
+    // Env.limit_act -> BoxSpace.project_to (P/spaces/box.py:180-184); np.clip propagates NaN (fminf/fmaxf would drop it)
+    __device__ static void limit_act(const float*, const float* lo, const float* hi, const float* a_raw, float* a) {
+#pragma unroll
+        for (int j = 0; j < A_; ++j) {
+            a[j] = fminf(fmaxf(a_raw[j], lo[j]), hi[j]);
+            if (isnan(a_raw[j])) a[j] = a_raw[j];
+        }
+    }
+    // DummyPolicy: act_space.sample_uniform() (P/policies/feed_forward/dummy.py:77-84)
+    __device__ static float sample_action(const float*, float lo, float hi, float u01, int) { return lo + (hi - lo) * u01; }
+};
+
 // =================================================================================================== OMO
 // OneMassOscillatorSim, P/environments/pysim/one_mass_oscillator.py:49-121
-struct Omo {
+struct Omo : EnvDefaults<1> {
     static constexpr int S = 2, A = 1, O = 2, H = 0, I = 2, P = 3, K = 4, KS = 4;
     static constexpr int REW = REW_QUADR, RADIAL = -1, CMAX = -1;
-    static constexpr bool SYMMETRIC_BOX = true;
-    static constexpr bool HAS_FINAL = true;  // FinalRewTask(factor 1e3, always_negative), :75-79
+    static constexpr int FINAL = FINAL_CONST_MALUS;  // FinalRewTask(factor 1e3, always_negative), :75-79
     enum { C_A10, C_A11, C_B1, C_AMAX };
     __device__ static void calc_consts(const Task&, const float* p, float* c) {  // _calc_constants :88-103
         float m = p[0], k = p[1], d = p[2];
@@ -189,11 +207,35 @@ struct Omo {
 
 // =================================================================================================== BoB
 // BallOnBeamSim, P/environments/pysim/ball_on_beam.py:41-136
-struct Bob {
+// V = 1: BallOnBeamDiscSim (ball_on_beam.py:139-161): the action space is DiscreteSpace({-max, 0, +max})
+template <int V>
+struct BobT : EnvDefaults<1> {
     static constexpr int S = 4, A = 1, O = 4, H = 0, I = 4, P = 8, K = 9, KS = 9;
     static constexpr int REW = REW_SCALED_EXP, RADIAL = -1;
-    static constexpr bool HAS_FINAL = false;
-    static constexpr bool SYMMETRIC_BOX = true;
+    // DiscreteSpace.project_to (P/spaces/discrete.py:104-131): an action that is np.isclose to one of the elements is
+    // kept as it is, anything else snaps to the closest element (argmin: the first of two equally close ones)
+    __device__ static void limit_act(const float* c, const float* lo, const float* hi, const float* a_raw, float* a) {
+        if (V == 0) { EnvDefaults<1>::limit_act(c, lo, hi, a_raw, a); return; }
+        float x = a_raw[0];
+        float e[3] = {lo[0], (lo[0] + hi[0]) * 0.5f, hi[0]};
+        float tol = 1e-8f + 1e-5f * fabsf(x);  // np.isclose(eles, cand): atol + rtol * |cand|
+        bool close = false;
+        int best = 0;
+        float bd = fabsf(x - e[0]);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float dk = fabsf(x - e[k]);
+            close |= dk <= tol;
+            if (dk < bd) { bd = dk; best = k; }
+        }
+        a[0] = close ? x : e[best];
+        if (isnan(x)) a[0] = x;
+    }
+    __device__ static float sample_action(const float* c, float lo, float hi, float u01, int) {
+        if (V == 0) return lo + (hi - lo) * u01;
+        int k = min((int)(u01 * 3.0f), 2);  // np.random.randint(3)
+        return k == 0 ? lo : (k == 1 ? (lo + hi) * 0.5f : hi);
+    }
     enum { C_MG, C_M, C_FRICT, C_OFF, C_INV_ZETA_BALL, C_J_BEAM, C_XMAX, C_AMAX, C_CMAX };
     static constexpr int CMAX = C_CMAX;
     __device__ static void calc_consts(const Task& T, const float* p, float* c) {  // _calc_constants :89-98
@@ -248,14 +290,16 @@ struct Bob {
     }
     __device__ static void init_hidden(const Task&, const float*, const float*, const float*, float*, bool) {}
 };
+using Bob = BobT<0>;
+using BobD = BobT<1>;
 
 // =================================================================================================== QQube
 // QQubeSwingUpSim, P/environments/pysim/quanser_qube.py:41-188
-struct QQ {
+// V = 1: QQubeStabSim (quanser_qube.py:191-222): same dynamics and spaces, init space around the upright pendulum
+template <int V>
+struct QQT : EnvDefaults<1> {
     static constexpr int S = 4, A = 1, O = 6, H = 0, I = 4, P = 11, K = 11, KS = 11;
     static constexpr int REW = REW_EXP, RADIAL = 1, CMAX = -1;
-    static constexpr bool HAS_FINAL = false;
-    static constexpr bool SYMMETRIC_BOX = true;
     enum { C_C0, C_C1, C_C2, C_C3, C_C4, C_KM, C_RM, C_DR, C_DP, C_TH_NEG, C_TH_POS };
     __device__ static void calc_consts(const Task&, const float* p, float* c) {  // _calc_constants :70-87
         float g = p[0], Rm = p[1], km = p[2], mr = p[3], Lr = p[4], Dr = p[5], mp = p[6], Lp = p[7], Dp = p[8];
@@ -313,6 +357,12 @@ struct QQ {
     }
     __device__ static void sample_init(const Task&, const float*, Rng& g, float* init) {  // :170
         const float d2r = PI_F / 180.0f;
+        if (V == 1) {  // :207-208: theta +-5 deg, alpha 175..185 deg, zero velocities
+            init[0] = g.uniform(-5.0f * d2r, 5.0f * d2r);
+            init[1] = g.uniform(175.0f * d2r, 185.0f * d2r);
+            init[2] = init[3] = 0.f;
+            return;
+        }
         init[0] = g.uniform(-2.0f * d2r, 2.0f * d2r);
         init[1] = g.uniform(-1.0f * d2r, 1.0f * d2r);
         init[2] = g.uniform(-0.5f * d2r, 0.5f * d2r);
@@ -323,14 +373,19 @@ struct QQ {
     }
     __device__ static void init_hidden(const Task&, const float*, const float*, const float*, float*, bool) {}
 };
+using QQ = QQT<0>;
+using QQSt = QQT<1>;
 
 // =================================================================================================== QCartPole
 // QCartPoleSwingUpSim, P/environments/pysim/quanser_cartpole.py:45-230, 507-587; rk4 591-655
-struct Qcp {
+// V = 1: QCartPoleStabSim (quanser_cartpole.py:441-504): the pole has to stay within +-15 deg of upright; quadratic
+// reward; FinalRewTask(state_dependent, time_dependent)
+template <int V>
+struct QcpT : EnvDefaults<1> {
     static constexpr int S = 4, A = 1, O = 5, H = 1, I = 4, P = 17, K = 16, KS = 16;
-    static constexpr int REW = REW_EXP, RADIAL = 1, CMAX = -1;
-    static constexpr bool HAS_FINAL = false;
-    static constexpr bool SYMMETRIC_BOX = true;
+    static constexpr int REW = V == 1 ? REW_QUADR : REW_EXP, RADIAL = 1, CMAX = -1;
+    static constexpr bool SYMMETRIC_BOX = V == 0;
+    static constexpr int FINAL = V == 1 ? FINAL_STATE_TIME : FINAL_NONE;
     enum { C_KA, C_ETA_M, C_KB, C_MTG, C_MPL2, C_MU, C_M00, C_MPL, C_M11, C_BEQ, C_BP, C_MPLG, C_TH_NEG, C_TH_POS,
            C_XMAX, C_XDMAX };
     __device__ static void calc_consts(const Task&, const float* p, float* c) {  // _calc_constants :145-155 + _dynamics
@@ -356,6 +411,13 @@ struct Qcp {
         c[C_XDMAX] = l_rail;
     }
     __device__ static void state_bounds(const float* c, float* lo, float* hi) {
+        if (V == 1) {  // :478-483, stab_thold = 15 deg
+            hi[0] = c[C_XMAX]; lo[0] = -c[C_XMAX];
+            lo[1] = (float)(PI_D - 15.0 / 180.0 * PI_D); hi[1] = (float)(PI_D + 15.0 / 180.0 * PI_D);
+            hi[2] = c[C_XDMAX]; lo[2] = -c[C_XDMAX];
+            hi[3] = (float)(2.0 * PI_D); lo[3] = -hi[3];
+            return;
+        }
         hi[0] = c[C_XMAX]; hi[1] = PI4_F; hi[2] = c[C_XDMAX]; hi[3] = PI20_F;
         for (int j = 0; j < 4; ++j) lo[j] = -hi[j];
     }
@@ -411,6 +473,13 @@ struct Qcp {
         o[4] = s[3];
     }
     __device__ static void sample_init(const Task& T, const float*, Rng& g, float* init) {  // :552-560
+        if (V == 1) {  // :485-490, max_init_th_offset = 8 deg
+            init[0] = g.uniform(-0.02f, 0.02f);
+            init[1] = g.uniform((float)(PI_D - 8.0 / 180.0 * PI_D), (float)(PI_D + 8.0 / 180.0 * PI_D));
+            init[2] = g.uniform(-0.02f, 0.02f);
+            init[3] = g.uniform((float)(-5.0 / 180.0 * PI_D), (float)(5.0 / 180.0 * PI_D));
+            return;
+        }
         float hi[4];
         if (T.wild_init == 0) { hi[0] = 0.25f; hi[1] = PI_F; hi[2] = 0.8f; hi[3] = PI_F; }
         else if (T.wild_init == 1) { hi[0] = 0.02f; hi[1] = 2.0f / 180.0f * PI_F; hi[2] = 0.f; hi[3] = 1.0f / 180.0f * PI_F; }
@@ -423,6 +492,46 @@ struct Qcp {
     __device__ static void init_hidden(const Task&, const float*, const float*, const float*, float* h, bool) {
         h[0] = 0.f;  // reset(): self._th_ddot = 0.0 (:103)
     }
+};
+using Qcp = QcpT<0>;
+using QcpSt = QcpT<1>;
+
+// =================================================================================================== Pendulum
+// PendulumSim, P/environments/pysim/pendulum.py:43-117
+struct Pend : EnvDefaults<1> {
+    static constexpr int S = 2, A = 1, O = 3, H = 0, I = 2, P = 5, K = 4, KS = 4;
+    // idcs=[1] in the reference (pendulum.py:87): the 2pi modulo is applied to the theta_dot error
+    static constexpr int REW = REW_EXP, RADIAL = 1, CMAX = -1;
+    enum { C_MGL2, C_DAMP, C_INV_J, C_AMAX };
+    __device__ static void calc_consts(const Task&, const float* p, float* c) {
+        float g = p[0], m = p[1], l = p[2];
+        c[C_MGL2] = m * g * l / 2.0f;            // :104
+        c[C_DAMP] = p[3];
+        c[C_INV_J] = 1.0f / (m * l * l / 3.0f);  // rod about its end
+        c[C_AMAX] = p[4];                        // torque_thold, _create_spaces :73-78
+    }
+    __device__ static void state_bounds(const float*, float* lo, float* hi) {  // :71
+        hi[0] = PI4_F; hi[1] = PI4_F; lo[0] = -PI4_F; lo[1] = -PI4_F;
+    }
+    __device__ static void act_bounds(const float* c, float* lo, float* hi) { hi[0] = c[C_AMAX]; lo[0] = -c[C_AMAX]; }
+    __device__ static void dynamics(const Task& T, const float* c, float* s, float*, const float* act, const float* ob) {
+        float sn, cs;
+        if (ob) sn = ob[0];
+        else sincos_fast(s[0], &sn, &cs);
+        float th_ddot = (act[0] - c[C_MGL2] * sn - c[C_DAMP] * s[1]) * c[C_INV_J];  // :103-106
+        s[1] += th_ddot * T.dt;  // symplectic Euler :109-110
+        s[0] += s[1] * T.dt;
+    }
+    __device__ static void observe(const float* s, float* o) {  // :91-92
+        sincos_fast(s[0], &o[0], &o[1]);
+        o[2] = s[1];
+    }
+    __device__ static void sample_init(const Task& T, const float*, Rng&, float* init) {  // SingularStateSpace :76
+        init[0] = T.init_fixed[0];
+        init[1] = T.init_fixed[1];
+    }
+    __device__ static void state_from_init(const float* init, float* s) { s[0] = init[0]; s[1] = init[1]; }
+    __device__ static void init_hidden(const Task&, const float*, const float*, const float*, float*, bool) {}
 };
 
 // =================================================================================================== QBB
@@ -453,11 +562,9 @@ __device__ inline float qbb_ik(float th, float r, float l) {
 }
 
 // QBallBalancerSim, P/environments/pysim/quanser_ball_balancer.py:49-337
-struct Qbb {
+struct Qbb : EnvDefaults<2> {
     static constexpr int S = 8, A = 2, O = 8, H = 2, I = 4, P = 20, K = 19, KS = 17;
     static constexpr int REW = REW_SCALED_EXP, RADIAL = -1;
-    static constexpr bool HAS_FINAL = false;
-    static constexpr bool SYMMETRIC_BOX = true;
     enum { C_AM, C_BEQV, C_JEQ, C_CKIN, C_OFFX, C_OFFY, C_TXP, C_TXN, C_TYP, C_TYN, C_BDR2, C_JBR, C_MR2, C_CKMGR2,
            C_ZETA, C_XMAX, C_CMAX, C_IK_X0, C_IK_Y0 };
     static constexpr int CMAX = C_CMAX;

@@ -211,6 +211,16 @@ _DEFAULTS = {
 }
 
 
+# QQubeStabSim / QCartPoleStabSim / BallOnBeamDiscSim share their base family's table (registered on the base classes,
+# default_randomizers.py:303-304, 375-376 and the MRO walk of create_default_randomizer :79-86); PendulumSim :208-229
+_DEFAULTS["qq-st"] = _DEFAULTS["qq-su"]
+_DEFAULTS["qcp-st"] = _DEFAULTS["qcp-su"]
+_DEFAULTS["bob-d"] = _DEFAULTS["bob"]
+_DEFAULTS["pend"] = [("gravity_const", "N", 10, 1e-3, inf), ("pole_mass", "N", 10, 1e-3, inf),
+                     ("pole_length", "N", 10, 1e-3, inf), ("pole_damping", "N", 10, 1e-3, inf),
+                     ("torque_thold", "N", 10, 1e-3, inf)]
+
+
 def default_randomizer_for(name: str, nominal: dict) -> DomainRandomizer:
     """The default randomizer of env family `name` built around the nominal parameter dict."""
     if name not in _DEFAULTS:
@@ -232,7 +242,10 @@ def create_default_randomizer(env) -> DomainRandomizer:
     from .wrappers import inner_env
 
     e = inner_env(env)
-    return default_randomizer_for(e.name, e.get_nominal_domain_param())
+    nominal = e.get_nominal_domain_param()
+    if e.name in ("qcp-su", "qcp-st"):
+        nominal = type(e).get_nominal_domain_param(long=False)  # the reference builds the table for the short pole (:312)
+    return default_randomizer_for(e.name, nominal)
 
 
 def create_zero_var_randomizer(env, eps: float = 1e-8) -> DomainRandomizer:

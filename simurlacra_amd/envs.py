@@ -19,7 +19,7 @@ import numpy as np
 
 from . import _lib as L
 from .exceptions import ShapeErr, TypeErr, ValueErr
-from .spaces import BoxSpace, CompoundSpace, EnvSpec, Polar2DPosVelSpace
+from .spaces import BoxSpace, CompoundSpace, DiscreteSpace, EnvSpec, Polar2DPosVelSpace, SingularStateSpace
 from .vec_env import VecSimEnv, nominal_params, param_names
 
 inf = float("inf")
@@ -57,9 +57,12 @@ class VecSimPyEnv(SimEnv):
 
     name: str = None
     _REW_KIND = {"omo": "QuadrErrRewFcn", "bob": "ScaledExpQuadrErrRewFcn", "qq-su": "ExpQuadrErrRewFcn",
-                 "qcp-su": "ExpQuadrErrRewFcn", "qbb": "ScaledExpQuadrErrRewFcn"}
+                 "qcp-su": "ExpQuadrErrRewFcn", "qbb": "ScaledExpQuadrErrRewFcn", "qq-st": "ExpQuadrErrRewFcn",
+                 "qcp-st": "QuadrErrRewFcn", "pend": "ExpQuadrErrRewFcn", "bob-d": "ScaledExpQuadrErrRewFcn"}
     _TASK_KIND = {"omo": "FinalRewTask(DesStateTask)", "bob": "DesStateTask", "qq-su": "RadiallySymmDesStateTask",
-                  "qcp-su": "RadiallySymmDesStateTask", "qbb": "DesStateTask"}
+                  "qcp-su": "RadiallySymmDesStateTask", "qbb": "DesStateTask", "qq-st": "RadiallySymmDesStateTask",
+                  "qcp-st": "FinalRewTask(RadiallySymmDesStateTask)", "pend": "RadiallySymmDesStateTask",
+                  "bob-d": "DesStateTask"}
 
     def __init__(self, dt: float, max_steps: int = inf, task_args: Optional[dict] = None, num_envs: int = 1,
                  device: int = 0, **flags):
@@ -448,5 +451,84 @@ class QBallBalancerSim(VecSimPyEnv):
         return h[0] if self._num_envs == 1 else h
 
 
+# ------------------------------------------------------------------------------------- remaining pysim families
+class QQubeStabSim(QQubeSwingUpSim):
+    """P/environments/pysim/quanser_qube.py:191-222"""
+
+    name = "qq-st"
+
+    def _spaces(self):
+        ss, os_, as_, _ = super()._spaces()
+        lab = ["theta", "alpha", "theta_dot", "alpha_dot"]
+        init = BoxSpace(np.array([-5.0 / 180 * PI, 175.0 / 180 * PI, 0, 0]), np.array([5.0 / 180 * PI, 185.0 / 180 * PI, 0, 0]),
+                        labels=lab)
+        return ss, os_, as_, init
+
+
+class QCartPoleStabSim(QCartPoleSwingUpSim):
+    """P/environments/pysim/quanser_cartpole.py:441-504 (ctor defaults long=True, simple_dynamics=True)"""
+
+    name = "qcp-st"
+    stab_thold = 15 / 180.0 * PI
+    max_init_th_offset = 8 / 180.0 * PI
+
+    def __init__(self, dt: float, max_steps: int = inf, task_args: Optional[dict] = None, long: bool = True,
+                 simple_dynamics: bool = True, num_envs: int = 1, device: int = 0):
+        super().__init__(dt, max_steps, task_args, long=long, simple_dynamics=simple_dynamics, wild_init="False",
+                         num_envs=num_envs, device=device)
+        self._ctor = dict(dt=dt, max_steps=max_steps, task_args=task_args, long=long, simple_dynamics=simple_dynamics,
+                          num_envs=num_envs, device=device)
+
+    def _spaces(self):
+        _, os_, as_, _ = super()._spaces()
+        l_rail = self._domain_param["rail_length"]
+        lab = ["x", "theta", "x_dot", "theta_dot"]
+        ss = BoxSpace(np.array([-l_rail / 2.0 + 0.15, PI - self.stab_thold, -l_rail, -2 * PI]),
+                      np.array([+l_rail / 2.0 - 0.15, PI + self.stab_thold, +l_rail, +2 * PI]), labels=lab)
+        init = BoxSpace(np.array([-0.02, PI - self.max_init_th_offset, -0.02, -5 / 180 * PI]),
+                        np.array([+0.02, PI + self.max_init_th_offset, +0.02, +5 / 180 * PI]), labels=lab)
+        return ss, os_, as_, init
+
+
+class PendulumSim(VecSimPyEnv):
+    """P/environments/pysim/pendulum.py:43-117"""
+
+    name = "pend"
+    _NOMINAL_F64 = dict(gravity_const=9.81, pole_mass=1.0, pole_length=1.0, pole_damping=0.05, torque_thold=3.5)
+
+    def __init__(self, dt: float, max_steps: int = inf, task_args: Optional[dict] = None,
+                 init_state: Optional[np.ndarray] = None, num_envs: int = 1, device: int = 0):
+        self._init_state = np.zeros(2) if init_state is None else np.asarray(init_state, dtype=np.float64)
+        if self._init_state.size != 2:
+            raise ShapeErr(given=self._init_state, expected_match=(2,))
+        super().__init__(dt, max_steps, task_args, num_envs=num_envs, device=device, init_state=self._init_state)
+        self._ctor = dict(dt=dt, max_steps=max_steps, task_args=task_args, init_state=self._init_state, num_envs=num_envs,
+                          device=device)
+
+    def _spaces(self):
+        max_state = np.array([4 * PI, 4 * PI])
+        max_obs = np.array([1.0, 1.0, np.inf])
+        tau_max = self._domain_param["torque_thold"]
+        return (BoxSpace(-max_state, max_state, labels=["theta", "theta_dot"]),
+                BoxSpace(-max_obs, max_obs, labels=["sin_theta", "cos_theta", "theta_dot"]),
+                BoxSpace(-tau_max, tau_max, shape=(1,), labels=["tau"]),
+                SingularStateSpace(self._init_state, labels=["theta", "theta_dot"]))
+
+    def observe(self, state):  # :91-92
+        s = np.asarray(state)
+        return np.array([np.sin(s[0]), np.cos(s[0]), s[1]])
+
+
+class BallOnBeamDiscSim(BallOnBeamSim):
+    """P/environments/pysim/ball_on_beam.py:139-161: three discrete torques {-max, 0, +max}"""
+
+    name = "bob-d"
+
+    def _spaces(self):
+        ss, os_, as_, init = super()._spaces()
+        lo, hi = as_.bounds
+        return ss, os_, DiscreteSpace(np.linspace(lo, hi, num=3, endpoint=True), labels=["tau"]), init
+
+
 ENV_CLASSES = {c.name: c for c in (OneMassOscillatorSim, BallOnBeamSim, QQubeSwingUpSim, QCartPoleSwingUpSim,
-                                   QBallBalancerSim)}
+                                   QBallBalancerSim, QQubeStabSim, QCartPoleStabSim, PendulumSim, BallOnBeamDiscSim)}

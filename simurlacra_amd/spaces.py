@@ -165,6 +165,68 @@ class CompoundSpace(Space):
         return self._spaces[idx].sample_uniform()
 
 
+class SingularStateSpace(BoxSpace):
+    """always returns the same initial state (P/spaces/singular.py:37-52)"""
+
+    def __init__(self, fixed_state: np.ndarray, labels=None):
+        super().__init__(fixed_state, fixed_state, labels=labels)
+        self._fixed_state = np.asarray(fixed_state, dtype=np.float64)
+
+    def sample_uniform(self, concrete_inf: float = 1e6) -> np.ndarray:
+        return self._fixed_state.copy()
+
+
+class DiscreteSpace(Space):
+    """finite set of elements, one per row (P/spaces/discrete.py:38-131)"""
+
+    def __init__(self, eles, labels=None):
+        eles = np.asarray(eles, dtype=np.float64)
+        self.eles = np.atleast_2d(eles if eles.ndim == 2 else eles.reshape(-1, 1))
+        self.bound_lo = np.min(self.eles, axis=0)
+        self.bound_up = np.max(self.eles, axis=0)
+        self._labels = np.array(labels, dtype=object) if labels is not None else np.full(self.shape, None, dtype=object)
+
+    def _members(self):
+        return self.eles, self._labels
+
+    @property
+    def shape(self):
+        return self.bound_lo.shape
+
+    @property
+    def labels(self):
+        return self._labels
+
+    @property
+    def num_ele(self) -> int:
+        return self.eles.shape[0]
+
+    @property
+    def flat_dim(self) -> int:
+        return self.eles.shape[1]
+
+    @property
+    def bound_abs_up(self) -> np.ndarray:
+        return np.max(np.abs(self.eles), axis=0)
+
+    def contains(self, cand: np.ndarray, verbose: bool = False) -> bool:
+        cand = np.asarray(cand)
+        if not cand.shape == self.shape:
+            raise ShapeErr(given=cand, expected_match=self)
+        if np.isnan(cand).any():
+            raise ValueErr(msg="At least one value is NaN!")
+        return bool(np.any(np.isclose(self.eles, cand.astype(self.eles.dtype))))
+
+    def sample_uniform(self, concrete_inf: float = 1e6) -> np.ndarray:
+        idx = np.random.randint(self.num_ele, size=1)
+        return self.eles[idx, :].flatten()
+
+    def project_to(self, ele: np.ndarray) -> np.ndarray:
+        if not self.contains(ele):
+            return self.eles[np.argmin(np.abs(ele - self.eles)), :]
+        return ele
+
+
 class EnvSpec:
     """P/utils/data_types.py:45-50"""
 

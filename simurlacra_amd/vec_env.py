@@ -57,8 +57,8 @@ def nominal_params(name, long=False):
 class VecSimEnv:
     """N environments of one Pyrado pysim family on one GPU."""
 
-    def __init__(self, name, n_envs, dt, max_steps=math.inf, task_args=None, device=0, simple_dynamics=False,
-                 long=False, wild_init="True"):
+    def __init__(self, name, n_envs, dt, max_steps=math.inf, task_args=None, device=0, simple_dynamics=None,
+                 long=None, wild_init="True", init_state=None):
         if name not in L.ENV_TYPES:
             raise ValueErr(msg=f"unknown environment name {name!r}; expected one of {sorted(L.ENV_TYPES)}")
         if not isinstance(dt, (int, float)):
@@ -69,6 +69,12 @@ class VecSimEnv:
             raise ValueErr(given=max_steps, ge_constraint="1")
         if not (isinstance(task_args, dict) or task_args is None):
             raise TypeErr(given=task_args, expected_type=dict)  # P/environments/pysim/base.py:70-71
+        # ctor defaults of the reference classes: QCartPoleStabSim(long=True, simple_dynamics=True)
+        # (quanser_cartpole.py:452-459), everything else False
+        if simple_dynamics is None:
+            simple_dynamics = name == "qcp-st"
+        if long is None:
+            long = name == "qcp-st"
         self._lib = L.load()
         self.name = name
         self.n_envs = int(n_envs)
@@ -82,6 +88,11 @@ class VecSimEnv:
         cfg.use_defaults = 1
         cfg.flags = self._flags
         cfg.wild_init = {"True": 0, "False": 1}.get(str(wild_init), 2)
+        if init_state is not None:  # PendulumSim(init_state=...): the fixed state of its SingularStateSpace
+            ist = np.asarray(init_state, dtype=np.float64).reshape(-1)
+            if ist.size != self.dims["S"]:
+                raise ShapeErr(given=ist, expected_match=(self.dims["S"],))
+            cfg.init_state[: ist.size] = list(map(float, ist))
         if task_args:
             cfg.use_defaults = 0
             des, qd, rd = self.default_task(name)
@@ -117,6 +128,10 @@ class VecSimEnv:
             "qq-su": (np.array([0.0, pi, 0.0, 0.0]), np.array([1.0, 1.0, 2e-2, 5e-3]), np.array([4e-3])),
             "qcp-su": (np.array([0.0, pi, 0.0, 0.0]), np.array([3e-1, 5e-1, 5e-3, 1e-3]), np.array([1e-3])),
             "qbb": (np.zeros(8), np.array([1e0, 1e0, 5e3, 5e3, 1e-2, 1e-2, 5e-1, 5e-1]), np.array([1e-2, 1e-2])),
+            "qq-st": (np.array([0.0, pi, 0.0, 0.0]), np.array([3.0, 4.0, 2.0, 2.0]), np.array([5e-2])),
+            "qcp-st": (np.array([0.0, pi, 0.0, 0.0]), np.array([5e-0, 1e1, 1e-2, 1e-2]), np.array([1e-3])),
+            "pend": (np.array([pi, 0.0]), np.array([1e-0, 1e-3]), np.array([1e-2])),
+            "bob-d": (np.zeros(4), np.array([1e5, 1e3, 1e3, 1e2]), np.array([1.0])),
         }[name]
 
     @staticmethod

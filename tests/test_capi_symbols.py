@@ -40,7 +40,8 @@ def test_static_tables_match_reference(lib, golden_dir):
     from simurlacra_amd import env_dims, nominal_params, param_names
 
     expect = {"omo": (2, 1, 2, 3, 0, 2), "bob": (4, 1, 4, 8, 0, 4), "qq-su": (4, 1, 6, 11, 0, 4),
-              "qcp-su": (4, 1, 5, 17, 1, 4), "qbb": (8, 2, 8, 20, 2, 4)}
+              "qcp-su": (4, 1, 5, 17, 1, 4), "qbb": (8, 2, 8, 20, 2, 4), "qq-st": (4, 1, 6, 11, 0, 4),
+              "qcp-st": (4, 1, 5, 17, 1, 4), "pend": (2, 1, 3, 5, 0, 2), "bob-d": (4, 1, 4, 8, 0, 4)}
     for name, t in L.ENV_TYPES.items():
         assert lib.vs_env_name(t).decode() == name
         d = env_dims(name)

@@ -21,9 +21,11 @@ pytestmark = pytest.mark.gpu
 
 torch = pytest.importorskip("torch")
 
-ENVS = ["omo", "bob", "qq-su", "qcp-su", "qbb"]
+ENVS = ["omo", "bob", "qq-su", "qcp-su", "qbb", "qq-st", "qcp-st", "pend", "bob-d"]
 KW = {"omo": dict(dt=0.02, max_steps=300), "bob": dict(dt=0.01, max_steps=500), "qq-su": dict(dt=0.004, max_steps=4000),
-      "qcp-su": dict(dt=0.002, max_steps=8000), "qbb": dict(dt=0.01, max_steps=500)}
+      "qcp-su": dict(dt=0.002, max_steps=8000), "qbb": dict(dt=0.01, max_steps=500),
+      "qq-st": dict(dt=0.01, max_steps=500), "qcp-st": dict(dt=0.01, max_steps=300),
+      "pend": dict(dt=0.02, max_steps=400, init_state=np.array([0.1, 0.2])), "bob-d": dict(dt=0.01, max_steps=500)}
 RTOL_S, ATOL_S = 1e-5, 2e-6  # ATOL_S is multiplied by max(1, state bound) per dimension: see state_atol()
 RTOL_R, ATOL_R = 2e-4, 1e-12
 
@@ -66,10 +68,14 @@ def bound_margin(ref, nstate, params):
 def check_step(env, L, ref, params, state, hidden, act, curr_step, exp, yielded=None):
     """exp: dict with state/obs/rew/done(/hidden) from the reference or the oracle (fp64)"""
     assert_state_close(ref, env.get(L.VS_STATE), exp["state"], params)
-    np.testing.assert_allclose(env.get(L.VS_OBS), exp["obs"], rtol=RTOL_S, atol=ATOL_S)
+    # observe(): tight against the oracle's observe of the kernel's OWN next state (tests the trig), and against the
+    # reference within what the state tolerance allows (an angle of 4 pi known to 1e-5 relative moves its sine by 1e-4)
+    own = ref.observe(env.get(L.VS_STATE).astype(np.float64))
+    np.testing.assert_allclose(env.get(L.VS_OBS), own, rtol=1e-6, atol=5e-7)
+    np.testing.assert_allclose(env.get(L.VS_OBS), exp["obs"], rtol=RTOL_S, atol=1e-5)
     np.testing.assert_allclose(env.get(L.VS_REW), exp["rew"], rtol=RTOL_R, atol=ATOL_R)
     if ref.H:
-        np.testing.assert_allclose(env.get(L.VS_HIDDEN), exp["hidden"], rtol=1e-4, atol=1e-4 if ref.name == "qcp-su" else 2e-6)
+        np.testing.assert_allclose(env.get(L.VS_HIDDEN), exp["hidden"], rtol=1e-4, atol=1e-4 if ref.name.startswith("qcp") else 2e-6)
     got_done = env.get(L.VS_DONE).astype(bool)
     margin = bound_margin(ref, exp["state"], params).min(axis=1)
     far = margin > 1e-5
@@ -190,9 +196,9 @@ def test_reset_golden_cases(vs, golden_dir, name):
             np.testing.assert_allclose(env.get(L.VS_HIDDEN), g["hidden"][sel], rtol=0, atol=5e-6)
         assert (env.get(L.VS_STEPCOUNT) == 0).all() and not env.get(L.VS_DONE).any()
         # derived constants: bounds and c_max per env (Q11) -- checked through their effect below and directly here
-        if name in ("bob", "qbb"):
+        if name in ("bob", "qbb", "bob-d"):
             K = env.get(L.VS_CONSTS)
-            cmax_col = {"bob": 8, "qbb": 16}[name]
+            cmax_col = {"bob": 8, "qbb": 16, "bob-d": 8}[name]
             np.testing.assert_allclose(K[:, cmax_col], g["c_max"][sel], rtol=2e-6)
         env.close()
 
@@ -208,14 +214,15 @@ def test_oracle_parity_seeded_batch(vs, name):
     params = ref.nominal_params(n)
     params *= 1 + 0.15 * rng.standard_normal(params.shape) * (params != 0)
     for j, pn in enumerate(ref.param_names):
-        if pn.startswith("voltage_thold") and name != "qbb":
+        if pn.startswith("voltage_thold") and name != "qbb":  # noqa: E501
             params[:, j] = np.where("neg" in pn, -1, 1) * rng.uniform(0, 0.4, n)
         if pn.startswith("offset") or pn == "ang_offset":
             params[:, j] = rng.uniform(-0.05, 0.05, n)
     params = f32(params).astype(np.float64)
     slo, shi, alo, ahi = ref.bounds(params)
-    state = f32(rng.uniform(-1, 1, slo.shape) * shi * np.where(rng.random(slo.shape) < 0.03, 1.001, 0.98)).astype(np.float64)
-    hidden = f32(rng.uniform(-1, 1, (n, ref.H)) * (100 if name == "qcp-su" else 0.3)).astype(np.float64)
+    mid, half = 0.5 * (slo + shi), 0.5 * (shi - slo)
+    state = f32(mid + rng.uniform(-1, 1, slo.shape) * half * np.where(rng.random(slo.shape) < 0.03, 1.001, 0.98)).astype(np.float64)
+    hidden = f32(rng.uniform(-1, 1, (n, ref.H)) * (100 if name.startswith("qcp") else 0.3)).astype(np.float64)
     act = f32(rng.uniform(-1.4, 1.4, alo.shape) * ahi).astype(np.float64)
     curr = rng.integers(0, KW[name]["max_steps"], n)
     curr[::17] = KW[name]["max_steps"] - 1
@@ -260,7 +267,7 @@ def test_init_space_sampling(vs, name):
     slo, shi, _, _ = ref.bounds(params)
     assert ((s >= slo) & (s <= shi)).all()
     eps = 1e-6
-    if name == "bob":
+    if name in ("bob", "bob-d"):
         lo0, hi0 = ref.init_bounds(params, 0)
         lo1, hi1 = ref.init_bounds(params, 1)
         in0 = ((s >= lo0 - eps) & (s <= hi0 + eps)).all(axis=1)
@@ -284,7 +291,7 @@ def test_init_space_sampling(vs, name):
     env.reset(seed=5)
     assert np.array_equal(env.get(L.VS_STATE), f32(s))
     env.reset(seed=6)
-    assert not np.array_equal(env.get(L.VS_STATE), f32(s))
+    assert np.array_equal(env.get(L.VS_STATE), f32(s)) == (name == "pend")  # SingularStateSpace: always the same state
     env.close()
 
 
@@ -330,7 +337,7 @@ def test_domain_randomization_on_device(vs, golden_dir, name):
     # constants follow the sampled params
     rng = np.random.default_rng(1)
     slo, shi, alo, ahi = ref.bounds(P)
-    state = f32(rng.uniform(-0.9, 0.9, slo.shape) * shi).astype(np.float64)
+    state = f32(0.5 * (slo + shi) + rng.uniform(-0.9, 0.9, slo.shape) * 0.5 * (shi - slo)).astype(np.float64)
     hidden = np.zeros((n, ref.H))
     act = f32(rng.uniform(-1.2, 1.2, alo.shape) * ahi).astype(np.float64)
     env.reset(init_state=f32(state))
@@ -343,7 +350,7 @@ def test_domain_randomization_on_device(vs, golden_dir, name):
     env.close()
 
 
-@pytest.mark.parametrize("name", ["omo", "bob", "qbb"])
+@pytest.mark.parametrize("name", ["omo", "bob", "qbb", "bob-d"])
 def test_random_rollout_kernel_with_auto_reset(vs, name):
     """vs_step_random (k fused steps, on-device uniform policy, auto-reset) recorded and replayed
     through the oracle lane by lane; completed-episode returns/lengths (ballot-compacted) must match the records"""
@@ -363,7 +370,12 @@ def test_random_rollout_kernel_with_auto_reset(vs, name):
     params = ref.nominal_params(n)
     _, _, alo, ahi = ref.bounds(params)
     assert (act >= alo[None] - 1e-6).all() and (act <= ahi[None] + 1e-6).all()
-    assert abs(act.mean()) < 0.02 * ahi.max() and abs(act.std() - (ahi - alo).mean() / np.sqrt(12)) < 0.02 * ahi.max()
+    if name == "bob-d":  # DiscreteSpace.sample_uniform: the three torques, a third each
+        vals, counts = np.unique(act, return_counts=True)
+        np.testing.assert_allclose(vals, [alo[0, 0], 0.0, ahi[0, 0]], rtol=1e-6, atol=1e-6)
+        assert (np.abs(counts / act.size - 1 / 3) < 0.01).all()
+    else:
+        assert abs(act.mean()) < 0.02 * ahi.max() and abs(act.std() - (ahi - alo).mean() / np.sqrt(12)) < 0.02 * ahi.max()
     # replay: obs == state for these envs (qbb: the hidden plate angles are re-derived by carrying them along)
     steps = np.zeros(n, dtype=np.int64)
     hidden = ref.reset(params, obs[0], init_is_full_state=True)["hidden"]
@@ -371,7 +383,7 @@ def test_random_rollout_kernel_with_auto_reset(vs, name):
     ep_ret, ep_len = [], []
     for t in range(T - 1):
         out = ref.step(obs[t], hidden, act[t], params, steps)
-        np.testing.assert_allclose(rew[t], out["rew"], rtol=RTOL_R, atol=1e-6 if name == "omo" else ATOL_R)
+        np.testing.assert_allclose(rew[t], out["rew"], rtol=RTOL_R, atol=1e-6 if name == "omo" else ATOL_R)  # noqa: E501
         margin = bound_margin(ref, out["state"], params).min(axis=1)
         far = margin > 1e-5
         assert np.array_equal(done[t][far], out["done"][far])
@@ -405,7 +417,7 @@ def test_random_rollout_kernel_with_auto_reset(vs, name):
 
 
 @pytest.mark.parametrize("auto_reset", [False, True])
-@pytest.mark.parametrize("name", ["qq-su", "qcp-su", "bob"])
+@pytest.mark.parametrize("name", ["qq-su", "qcp-su", "bob", "qcp-st", "pend", "bob-d"])
 def test_rollout_kernel_equals_step_kernel(vs, name, auto_reset):
     """k fused steps == k single-step launches fed with the recorded actions: bit-exact.  Without auto-reset a lane
     that finished freezes in the fused kernel (rollout() stops at done) while vs_step keeps stepping, so lanes are
@@ -413,7 +425,7 @@ def test_rollout_kernel_equals_step_kernel(vs, name, auto_reset):
     L = vs._lib
     n, T = 2048, 64
     kw = dict(KW[name])
-    if name == "qq-su":
+    if name in ("qq-su", "pend"):
         kw["max_steps"] = 40  # time-outs inside the window
     a = vs.VecSimEnv(name, n, **kw)
     b = vs.VecSimEnv(name, n, **kw)

@@ -12,7 +12,9 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 KW = {"omo": dict(dt=0.02, max_steps=300), "bob": dict(dt=0.01, max_steps=500), "qq-su": dict(dt=0.004, max_steps=4000),
-      "qcp-su": dict(dt=0.002, max_steps=8000), "qbb": dict(dt=0.01, max_steps=500)}
+      "qcp-su": dict(dt=0.002, max_steps=8000), "qbb": dict(dt=0.01, max_steps=500),
+      "qq-st": dict(dt=0.01, max_steps=500), "qcp-st": dict(dt=0.01, max_steps=300),
+      "pend": dict(dt=0.02, max_steps=400, init_state=np.array([0.1, 0.2])), "bob-d": dict(dt=0.01, max_steps=500)}
 ENVS = list(KW)
 
 
@@ -39,7 +41,7 @@ def test_single_env_surface_follows_golden_trajectory(vs, golden_dir, name):
         assert env.curr_step == 0
         for t in range(12):
             env.state = g["state"][i, t].copy()  # one-step parity: follow the reference states
-            if name == "qcp-su" or name == "qbb":
+            if name in ("qcp-su", "qcp-st", "qbb"):
                 env.vec.put(vs._lib.VS_HIDDEN, g["hidden"][i, t][None].astype(np.float32))
             o, r, d, info = env.step(g["act"][i, t].copy())
             assert isinstance(r, float) and isinstance(d, bool) and info == {}

@@ -12,7 +12,9 @@ import simurlacra_amd as vs
 from simurlacra_amd.sampling import ParallelRolloutSampler, StepSequence
 
 KW = {"omo": dict(dt=0.02, max_steps=300), "bob": dict(dt=0.01, max_steps=500), "qq-su": dict(dt=0.004, max_steps=4000),
-      "qcp-su": dict(dt=0.002, max_steps=8000), "qbb": dict(dt=0.01, max_steps=500)}
+      "qcp-su": dict(dt=0.002, max_steps=8000), "qbb": dict(dt=0.01, max_steps=500),
+      "qq-st": dict(dt=0.01, max_steps=500), "qcp-st": dict(dt=0.01, max_steps=300),
+      "pend": dict(dt=0.02, max_steps=400, init_state=np.array([0.1, 0.2])), "bob-d": dict(dt=0.01, max_steps=500)}
 ENVS = list(KW)
 
 
@@ -68,7 +70,7 @@ def test_set_seed_kat(golden_dir):
 def test_default_randomizer_tables_match_reference(golden_dir, name):
     tab = json.load(open(os.path.join(golden_dir, "randomizers.json")))[name]
     env = make(name)
-    assert {k: float(v) for k, v in env.get_nominal_domain_param().items()} == tab["nominal"]
+    assert {k: float(v) for k, v in type(env).get_nominal_domain_param().items()} == tab["nominal"]
     rz = vs.create_default_randomizer(env)
     assert len(rz.domain_params) == len(tab["randomizer"])
     for dp, row in zip(rz.domain_params, tab["randomizer"]):
@@ -121,13 +123,13 @@ def test_env_spaces_and_task_follow_domain_params(golden_dir, name):
         np.testing.assert_allclose(env.state_space.bound_lo, g["state_lo"][i], rtol=1e-15)
         np.testing.assert_allclose(env.state_space.bound_up, g["state_hi"][i], rtol=1e-15)
         np.testing.assert_allclose(env.act_space.bound_up, g["act_hi"][i], rtol=1e-15)
-        if name == "bob":
+        if name in ("bob", "bob-d"):
             lo = np.concatenate([env.init_space.subspace(0).bound_lo, env.init_space.subspace(1).bound_lo])
             np.testing.assert_allclose(lo, g["init_lo"][i], rtol=1e-14)
         else:
             np.testing.assert_allclose(env.init_space.bound_lo, g["init_lo"][i], rtol=1e-14)
             np.testing.assert_allclose(env.init_space.bound_up, g["init_hi"][i], rtol=1e-14)
-        if name in ("bob", "qbb"):
+        if name in ("bob", "qbb", "bob-d"):
             assert env.task.rew_fcn.c_max == pytest.approx(float(g["c_max"][i]), rel=1e-13)
     assert env.name == name and env.spec.act_space == env.act_space
     assert set(env.supported_domain_param) == set(names)
