@@ -78,6 +78,9 @@ enum vs_buffer {
 /* vs_task_cfg.flags */
 #define VS_FLAG_SIMPLE_DYNAMICS 1 /* qcp / qbb ctor arg simple_dynamics=True */
 #define VS_FLAG_LONG_POLE 2       /* qcp ctor arg long=True (changes the nominal pole only) */
+#define VS_FLAG_ACT_NORM 4        /* ActNormWrapper fused into the step: incoming actions live in [-1, 1] and are mapped to
+                                     lb + (a + 1) (ub - lb) / 2 before anything else sees them
+                                     (P/environment_wrappers/action_normalization.py:66-75) */
 
 /* Task / ctor configuration. Zero-initialise and set `use_defaults = 1` to get the reference defaults
  * (_create_task of each env).  Q and R are diagonal (all reference defaults are). */
@@ -144,6 +147,13 @@ int vs_set_params_uniform(vs_handle h, const float* params);
 /* DomainRandomizer.randomize + get_params on device (P/domain_randomization/domain_randomizer.py:123-227):
  * Normal/Uniform draws (Philox4x32-10 keyed by seed), clipped; parameters without a spec keep their value. */
 int vs_sample_params(vs_handle h, const vs_dp_spec* specs, int n_specs, uint64_t seed, const uint8_t* mask);
+/* DomainRandWrapperBuffer (P/environment_wrappers/domain_randomization.py:151-261): a buffer of n_sets domain-parameter
+ * sets, f32 [P][n_sets] (host memory); at each of its resets an env takes the next set (selection 0 = cyclic: lane i starts
+ * at set (global index i) mod n_sets and advances by one per reset) or a random one (selection 1, Philox).
+ * n_sets = 0 removes the buffer.  Mutually exclusive with vs_set_randomizer. */
+int vs_set_param_buffer(vs_handle h, const float* params_soa, int n_sets, int selection);
+/* toggle VS_FLAG_ACT_NORM after creation */
+int vs_set_act_norm(vs_handle h, int on);
 /* DomainRandWrapperLive (P/environment_wrappers/domain_randomization.py:135-148): remember specs and redraw the
  * parameters of an env at each of its resets (vs_reset without explicit params, and auto-reset). n_specs = 0 disables. */
 int vs_set_randomizer(vs_handle h, const vs_dp_spec* specs, int n_specs);

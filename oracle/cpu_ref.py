@@ -200,6 +200,10 @@ class EnvRef:
         params = np.asarray(params, dtype=self.dtype)
         curr_step = np.asarray(curr_step, dtype=np.int64)
         slo, shi, alo, ahi = self.bounds(params)
+        if self.flags.get("act_norm", False):
+            # ActNormWrapper._process_act (P/environment_wrappers/action_normalization.py:66-72): the inner env only ever
+            # sees the de-normalised action
+            act_raw = alo + (act_raw + f(1)) * (ahi - alo) / f(2)
 
         # reward on the pre-step state and the unclipped action (Q3)
         rew = self.step_rew(state, act_raw, params)

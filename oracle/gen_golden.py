@@ -335,6 +335,45 @@ def gen_ik(seed=3):
     return dict(th=np.array(th), r=np.array(r), l=np.array(l), ang=np.array(ang))
 
 
+def gen_wrappers():
+    """ActNormWrapper (action_normalization.py:63-89) single steps and the set order of a cyclic DomainRandWrapperBuffer
+    (domain_randomization.py:151-261), straight from the reference classes"""
+    from pyrado.environment_wrappers.action_normalization import ActNormWrapper
+    from pyrado.environment_wrappers.domain_randomization import DomainRandWrapperBuffer
+
+    out = {}
+    for name in ("qq-su", "qbb"):
+        cls, kw = ENVS[name]
+        env = ActNormWrapper(cls(**kw))
+        rng = np.random.default_rng(7)
+        rec = {k: [] for k in ("state", "act", "nstate", "rew", "done", "obs")}
+        for i in range(48):
+            env.reset()
+            s = rng.uniform(env.state_space.bound_lo, env.state_space.bound_up) * 0.8
+            env.state = s.copy()
+            if name == "qbb":
+                env.wrapped_env.plate_angs = np.zeros(2)
+            a = rng.uniform(-1.4, 1.4, size=env.act_space.shape)
+            obs, rew, done, _ = env.step(a.copy())
+            for k, v in zip(("state", "act", "nstate", "rew", "done", "obs"), (s, a, np.array(env.state), rew, done, obs)):
+                rec[k].append(v)
+        assert np.array_equal(env.act_space.bound_up, np.ones(env.act_space.shape))
+        for k, v in rec.items():
+            out[f"{name.replace('-', '_')}_{k}"] = np.array(v)
+    cls, kw = ENVS["omo"]
+    e = cls(**kw)
+    torch.manual_seed(0)
+    w = DomainRandWrapperBuffer(e, create_default_randomizer(e), selection="cyclic")
+    w.fill_buffer(5)
+    out["omo_buffer"] = np.array([[float(d[k]) for k in ("mass", "stiffness", "damping")] for d in w.buffer])
+    seq = []
+    for i in range(12):
+        w.reset()
+        seq.append([w.domain_param[k] for k in ("mass", "stiffness", "damping")])
+    out["omo_buffer_seq"] = np.array(seq)
+    return out
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     m_step = {"omo": 256, "bob": 256, "qq-su": 256, "qcp-su": 256, "qbb": 128, "qq-st": 192, "qcp-st": 192, "pend": 192,
@@ -353,6 +392,8 @@ def main():
     if force or not os.path.exists(os.path.join(OUT, "cfg1_omo_500.npz")):
         np.savez_compressed(os.path.join(OUT, "cfg1_omo_500.npz"), **gen_cfg1())
         np.savez_compressed(os.path.join(OUT, "qbb_ik.npz"), **gen_ik())
+    if force or not os.path.exists(os.path.join(OUT, "wrappers.npz")):
+        np.savez_compressed(os.path.join(OUT, "wrappers.npz"), **gen_wrappers())
     with open(os.path.join(OUT, "randomizers.json"), "w") as fh:
         json.dump(gen_randomizer_tables(), fh, indent=1, sort_keys=True)
     # seed KAT straight from the reference function (table also in Pyrado/tests/test_set_seed.py:35-54)

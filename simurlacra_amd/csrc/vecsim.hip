@@ -41,6 +41,8 @@ struct Dev {
     const DrSpecs* dr;  // device copy of the live randomizer
     uint32_t idx0;      // global index of lane 0: every Philox stream is keyed by (idx0 + lane), so results do not depend
                         // on how a set of envs is split into handles, batches or GPUs
+    const float* pbuf;  // DomainRandWrapperBuffer: [P][pbuf_n] parameter sets (nullptr: none)
+    int pbuf_n, pbuf_mode;  // number of sets; 0 cyclic, 1 random
     int dr_n;           // its number of specs, by value: the reset path must not wait on a load to learn there is none
     float* ep_ret;
     int *ep_len, *ep_env;
@@ -86,6 +88,14 @@ template <class E>
 __device__ __forceinline__ StepOut step_one(const Task& T, const float* c, float* s, float* h, const float* a_raw,
                                             int& step, bool& yielded, const float* ob) {
     StepOut o;
+    float an[E::A];
+    if (T.flags & VS_FLAG_ACT_NORM) {  // ActNormWrapper._process_act (action_normalization.py:66-72)
+        float lb[E::A], ub[E::A];
+        E::act_bounds(c, lb, ub);
+#pragma unroll
+        for (int j = 0; j < E::A; ++j) an[j] = lb[j] + (a_raw[j] + 1.0f) * (ub[j] - lb[j]) / 2.0f;
+        a_raw = an;
+    }
 #ifdef VS_ABLATE_REWARD  // diagnostic builds only (profiling by ablation); never defined in the shipped library
     o.rew = a_raw[0];
 #else
@@ -181,6 +191,20 @@ template <class E>
 __device__ __forceinline__ void reset_lane_sampled(const Task& T, const Dev& d, bool with_dr, int i, uint64_t seed,
                                                    uint64_t epi, float* c, float* s, float* h) {
     if (with_dr && d.dr_n > 0) redraw_lane_params<E>(T, d, d.dr, i, seed, epi, c);
+    if (with_dr && d.pbuf_n > 0) {
+        // DomainRandWrapperBuffer.reset (domain_randomization.py:236-251): next set of the ring, or a random one
+        uint32_t k;
+        if (d.pbuf_mode == 0) k = (uint32_t)(((uint64_t)d.idx0 + (uint64_t)i + epi) % (uint64_t)d.pbuf_n);
+        else k = Rng::philox(seed, d.idx0 + (uint32_t)i, RNG_PARAM, epi).x % (uint32_t)d.pbuf_n;
+        float p[E::P];
+#pragma unroll
+        for (int q = 0; q < E::P; ++q) p[q] = d.pbuf[(size_t)q * d.pbuf_n + k];
+        E::calc_consts(T, p, c);
+#pragma unroll
+        for (int q = 0; q < E::P; ++q) d.params[(size_t)q * d.ld + i] = p[q];
+#pragma unroll
+        for (int q = 0; q < E::K; ++q) d.consts[(size_t)q * d.ld + i] = c[q];
+    }
     Rng g(seed, d.idx0 + (uint32_t)i, RNG_INIT, epi);
     float init[E::I];
     E::sample_init(T, c, g, init);
@@ -344,7 +368,8 @@ __device__ __forceinline__ void rollout_body(const Task& T, const Dev& d, int k_
         for (int j = 0; j < E::A; ++j) {
             unsigned e = sub * E::A + j;  // wave-uniform element index
             uint32_t bits = e == 0 ? blk.x : e == 1 ? blk.y : e == 2 ? blk.z : blk.w;
-            a[j] = E::sample_action(c, alo[j], ahi[j], Rng::to_u01(bits), j);  // act_space.sample_uniform()
+            bool nrm = (T.flags & VS_FLAG_ACT_NORM) != 0;  // the policy then acts in the wrapper's space [-1, 1]
+            a[j] = E::sample_action(c, nrm ? -1.0f : alo[j], nrm ? 1.0f : ahi[j], Rng::to_u01(bits), j);  // act_space.sample_uniform()
         }
         if (REC) {
             size_t tb = (size_t)t;
@@ -513,8 +538,11 @@ __global__ __launch_bounds__(BLOCK) void k_reset(Task T, Dev d, const float* __r
     if (init == nullptr || !valid) {
         reset_lane_sampled<E>(T, d, valid, i, seed, 0ull, c, s, h);
     } else {
-        // DomainRandWrapperLive.reset with an explicit init_state still redraws the params
-        if (d.dr_n > 0) redraw_lane_params<E>(T, d, d.dr, i, seed, 0ull, c);
+        // DomainRandWrapperLive / Buffer .reset with an explicit init_state still redraws the params
+        if (d.dr_n > 0 || d.pbuf_n > 0) {
+            float s_tmp[E::S], h_tmp[E::H > 0 ? E::H : 1];
+            reset_lane_sampled<E>(T, d, true, i, seed, 0ull, c, s_tmp, h_tmp);  // params + constants (state discarded)
+        }
         if (full_state) {
 #pragma unroll
             for (int j = 0; j < E::S; ++j) s[j] = init[(size_t)j * pitch + i];  // copied verbatim (base.py:184-188)
@@ -648,6 +676,7 @@ struct vs_env {
     DrSpecs dr{};                 // host copy of the live randomizer
     DrSpecs* d_dr = nullptr;      // its device copy (Dev::dr)
     DrSpecs* d_specs = nullptr;   // device scratch for vs_sample_params
+    float* d_pbuf = nullptr;      // DomainRandWrapperBuffer parameter sets
     bool auto_reset = false;
     uint64_t ar_seed = 0;
     bool uniform = true;
@@ -767,7 +796,7 @@ static int check_specs(vs_handle h, const vs_dp_spec* specs, int n, DrSpecs* out
 template <class E>
 static void launch_step(vs_handle h, const float* act, long es, long ds) {
     dim3 g = grid_for(h->d.ld), b(BLOCK);
-    bool uni = h->uniform && h->dr.n == 0;
+    bool uni = h->uniform && h->dr.n == 0 && h->d.pbuf_n == 0;
 #define LS(U, AR) hipLaunchKernelGGL((k_step<E, U, AR>), g, b, 0, h->stream, h->task, h->d, act, es, ds, h->ar_seed)
     if (h->auto_reset) { if (uni) LS(true, true); else LS(false, true); }
     else { if (uni) LS(true, false); else LS(false, false); }
@@ -946,6 +975,7 @@ int vs_destroy(vs_handle h) {
     for (void* p : h->allocs) (void)hipFree(p);
     if (h->stage) (void)hipFree(h->stage);
     if (h->stage_mask) (void)hipFree(h->stage_mask);
+    if (h->d_pbuf) (void)hipFree(h->d_pbuf);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
     return VS_OK;
@@ -1030,11 +1060,39 @@ int vs_set_randomizer(vs_handle h, const vs_dp_spec* specs, int n_specs) {
     int rc = check_specs(h, specs, n_specs, &dr);
     if (rc) return rc;
     HIPCHK(h, hipSetDevice(h->device));
+    if (dr.n > 0 && h->d.pbuf_n > 0) return fail(h, VS_ERR_STATE, "vs_set_randomizer: a parameter buffer is set");
     h->dr = dr;
     h->d.dr_n = dr.n;
     HIPCHK(h, hipMemcpyAsync(h->d_dr, &h->dr, sizeof(DrSpecs), hipMemcpyHostToDevice, h->stream));
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (n_specs > 0) h->uniform = false;
+    return VS_OK;
+}
+
+int vs_set_param_buffer(vs_handle h, const float* params_soa, int n_sets, int selection) {
+    if (!h || n_sets < 0 || (n_sets > 0 && !params_soa) || selection < 0 || selection > 1)
+        return fail(h, VS_ERR_ARG, "vs_set_param_buffer: bad argument");
+    if (n_sets > 0 && h->dr.n > 0) return fail(h, VS_ERR_STATE, "vs_set_param_buffer: a live randomizer is set");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->d_pbuf) { HIPCHK(h, hipFree(h->d_pbuf)); h->d_pbuf = nullptr; }
+    h->d.pbuf = nullptr;
+    h->d.pbuf_n = 0;
+    h->d.pbuf_mode = selection;
+    if (n_sets == 0) return VS_OK;
+    size_t bytes = (size_t)ENV_INFO[h->type].P * n_sets * sizeof(float);
+    HIPCHK(h, hipMalloc((void**)&h->d_pbuf, bytes));
+    HIPCHK(h, hipMemcpy(h->d_pbuf, params_soa, bytes, hipMemcpyHostToDevice));
+    h->d.pbuf = h->d_pbuf;
+    h->d.pbuf_n = n_sets;
+    h->uniform = false;
+    return VS_OK;
+}
+
+int vs_set_act_norm(vs_handle h, int on) {
+    if (!h) return VS_ERR_ARG;
+    if (on) h->task.flags |= VS_FLAG_ACT_NORM;
+    else h->task.flags &= ~VS_FLAG_ACT_NORM;
     return VS_OK;
 }
 

@@ -25,7 +25,7 @@ from . import _lib as L
 from .exceptions import TypeErr, ValueErr
 from .policies import DummyPolicy
 from .seeding import derive_seed, get_base_seed, set_seed
-from .wrappers import DomainRandWrapperLive, inner_env, typed_env
+from .wrappers import ActNormWrapper, DomainRandWrapperBuffer, DomainRandWrapperLive, inner_env, typed_env
 
 NO_SEED = object()
 
@@ -183,7 +183,9 @@ class ParallelRolloutSampler:
                                         task_args=ctor.pop("task_args") or None, device=dev, **ctor)
         v = self._vecs[key]
         v.set_randomizer([])
+        v.set_param_buffer(None)
         v.set_params_uniform(base.domain_param)
+        v.set_act_norm(typed_env(self.env, ActNormWrapper) is not None)  # the policy then acts in [-1, 1]
         return v
 
     def _run_batch(self, work, first_index, eval):
@@ -214,6 +216,11 @@ class ParallelRolloutSampler:
             v.set_params(mat)
         elif live is not None:
             v.sample_params(live.randomizer.device_specs(), seed=lane_key ^ 0xD1B54A32D192ED03)
+        else:
+            ring = typed_env(self.env, DomainRandWrapperBuffer)
+            if ring is not None and ring.buffer:
+                # rollout number r takes set r mod len(buffer) (cyclic) or a random one: the ring of the reference, per lane
+                v.set_param_buffer([ring.buffer] if isinstance(ring.buffer, dict) else ring.buffer, ring.selection)
         inits = [w[0] for w in work]
         v.set_auto_reset(False)
         v.reset(seed=lane_key)  # init-space sample for every lane ...

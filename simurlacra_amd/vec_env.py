@@ -231,6 +231,34 @@ class VecSimEnv:
         arr, n = self._specs(specs or [])
         self._check(self._lib.vs_set_randomizer(self._h, arr, n), "vs_set_randomizer")
 
+    def set_param_buffer(self, param_sets, selection="cyclic"):
+        """DomainRandWrapperBuffer on the device. param_sets: list of dicts (missing names keep the nominal value) or
+        array [B, P]; None / empty removes the buffer."""
+        if selection not in ("cyclic", "random"):
+            raise ValueErr(given=selection, eq_constraint="cyclic or random")
+        if param_sets is None or len(param_sets) == 0:
+            self._check(self._lib.vs_set_param_buffer(self._h, None, 0, 0), "vs_set_param_buffer")
+            return
+        if isinstance(param_sets[0], dict):
+            base = nominal_params(self.name, long=bool(self._flags & L.VS_FLAG_LONG_POLE))
+            mat = np.tile(base, (len(param_sets), 1))
+            for b, dct in enumerate(param_sets):
+                for k, v in dct.items():
+                    if k not in self.param_names:
+                        raise ValueErr(msg=f"unsupported domain parameter {k!r} for env {self.name}")
+                    mat[b, self.param_names.index(k)] = float(np.asarray(v).reshape(-1)[0])
+        else:
+            mat = np.asarray(param_sets, dtype=np.float32)
+            if mat.ndim != 2 or mat.shape[1] != self.dims["P"]:
+                raise ShapeErr(given=mat, expected_match=(len(param_sets), self.dims["P"]))
+        soa = np.ascontiguousarray(mat.T, dtype=np.float32)
+        self._check(self._lib.vs_set_param_buffer(self._h, soa.ctypes.data_as(C.c_void_p), soa.shape[1],
+                                                  0 if selection == "cyclic" else 1), "vs_set_param_buffer")
+
+    def set_act_norm(self, on=True):
+        """Fuse ActNormWrapper into the kernels: incoming actions are in [-1, 1]."""
+        self._check(self._lib.vs_set_act_norm(self._h, int(bool(on))), "vs_set_act_norm")
+
     # ------------------------------------------------------------------------------------------------ reset / step
     def reset(self, init_state=None, mask=None, seed=0):
         """SimPyEnv.reset for all (masked) envs. init_state: None (sample init space) or [N, I] / [N, S]."""

@@ -3,13 +3,14 @@ Environment wrappers on the named path: EnvWrapper (P/environment_wrappers/base.
 DomainRandWrapper / DomainRandWrapperLive (P/environment_wrappers/domain_randomization.py:43-148) and the chain helpers
 of P/environment_wrappers/utils.py.  Pure delegation, as in the reference.
 """
-from typing import Optional
+from random import randint
+from typing import List, Optional, Union
 
 import numpy as np
 
 from .domain_randomization import DomainRandomizer
 from .envs import SimEnv
-from .exceptions import ShapeErr, TypeErr
+from .exceptions import ShapeErr, TypeErr, ValueErr
 
 
 class EnvWrapper:
@@ -201,3 +202,113 @@ class DomainRandWrapperLive(DomainRandWrapper):
 
     def device_randomization(self, on: bool = True):
         self.vec.set_randomizer(self._randomizer.device_specs() if on else [])
+
+
+class DomainRandWrapperBuffer(DomainRandWrapper):
+    """Cycles through (or draws from) a buffer of domain-parameter sets at every reset
+    (P/environment_wrappers/domain_randomization.py:151-261)."""
+
+    def __init__(self, wrapped_env, randomizer: Optional[DomainRandomizer], selection: Optional[str] = "cyclic"):
+        if selection not in ["cyclic", "random"]:
+            raise ValueErr(given=selection, eq_constraint="cyclic or random")
+        super().__init__(wrapped_env, randomizer)
+        self._ring_idx = None
+        self._buffer = None
+        self.selection = selection
+
+    @property
+    def ring_idx(self) -> int:
+        return self._ring_idx
+
+    @ring_idx.setter
+    def ring_idx(self, idx: int):
+        if not isinstance(idx, int) or not 0 <= idx < len(self._buffer):
+            raise ValueErr(given=idx, ge_constraint="0 (int)", l_constraint=len(self._buffer))
+        self._ring_idx = idx
+
+    @property
+    def selection(self) -> str:
+        return self._selection
+
+    @selection.setter
+    def selection(self, selection: str):
+        if selection not in ["cyclic", "random"]:
+            raise ValueErr(given=selection, eq_constraint="cyclic or random")
+        self._selection = selection
+
+    def fill_buffer(self, num_domains: int):
+        if self._randomizer is None:
+            raise TypeErr(msg="The randomizer must not be None to call fill_buffer()!")
+        if not isinstance(num_domains, int) or num_domains < 0:
+            raise ValueErr(given=num_domains, g_constraint="0 (int)")
+        self._randomizer.randomize(num_domains)
+        self._buffer = self._randomizer.get_params(-1, fmt="list", dtype="numpy")
+        self._ring_idx = 0
+
+    @property
+    def buffer(self):
+        return self._buffer
+
+    @buffer.setter
+    def buffer(self, buffer: Union[List[dict], dict]):
+        if not (isinstance(buffer, list) or isinstance(buffer, dict)):
+            raise TypeErr(given=buffer, expected_type=[list, dict])
+        self._buffer = buffer
+
+    def reset(self, init_state: np.ndarray = None, domain_param: dict = None) -> np.ndarray:
+        if domain_param is None:
+            if isinstance(self._buffer, dict):
+                domain_param = self._buffer
+            elif isinstance(self._buffer, list):
+                domain_param = self._buffer[self._ring_idx]
+                if self._selection == "cyclic":
+                    self._ring_idx = (self._ring_idx + 1) % len(self._buffer)
+                elif self._selection == "random":
+                    self._ring_idx = randint(0, len(self._buffer) - 1)
+            else:
+                raise TypeErr(given=self._buffer, expected_type=[dict, list])
+        return super().reset(init_state=init_state, domain_param=domain_param)
+
+    def device_buffer(self, on: bool = True):
+        """Hand the buffer to the kernels (vs_set_param_buffer): every lane walks the ring at its own resets."""
+        buf = [self._buffer] if isinstance(self._buffer, dict) else self._buffer
+        self.vec.set_param_buffer(buf if on else None, self._selection)
+
+
+class EnvWrapperAct(EnvWrapper):
+    """Base of the wrappers that modify the action (P/environment_wrappers/base.py:288-330)."""
+
+    def _process_act(self, act: np.ndarray) -> np.ndarray:
+        raise NotImplementedError
+
+    def _process_act_space(self, space):
+        return space
+
+    def step(self, act: np.ndarray) -> tuple:
+        return self._wrapped_env.step(self._process_act(act))
+
+    @property
+    def act_space(self):
+        return self._process_act_space(self._wrapped_env.act_space)
+
+
+class ActNormWrapper(EnvWrapperAct):
+    """Normalises the action space to [-1, 1] (P/environment_wrappers/action_normalization.py:63-89).
+
+    On an env object the de-normalisation happens here on the host, exactly as in the reference; `device_fuse()` moves it
+    into the step kernels (VS_FLAG_ACT_NORM) for batched use, after which `vec.step` / `vec.step_random` take and draw
+    normalised actions."""
+
+    def _process_act(self, act: np.ndarray) -> np.ndarray:
+        lb, ub = self.wrapped_env.act_space.bounds
+        return lb + (act + 1) * (ub - lb) / 2
+
+    def _process_act_space(self, space):
+        from .spaces import BoxSpace
+
+        if not isinstance(space, BoxSpace):
+            raise NotImplementedError("Only implemented ActNormWrapper._process_act_space() for BoxSpace!")
+        return BoxSpace(-np.ones(space.shape), np.ones(space.shape), labels=space.labels)
+
+    def device_fuse(self, on: bool = True):
+        self.vec.set_act_norm(on)

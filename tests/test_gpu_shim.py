@@ -237,3 +237,70 @@ def test_vs_step_replays_exactly_from_a_hip_graph(vs):
     for which in (L.VS_STATE, L.VS_STEPCOUNT, L.VS_RETURNS, L.VS_EPSTAT_COUNT, L.VS_EPSTAT_RETSUM):
         assert np.array_equal(eager.get(which), graphed.get(which))
     assert eager.get(L.VS_EPSTAT_COUNT).sum() > 500  # short OMO episodes: auto-resets happened inside the graph
+
+
+def test_act_norm_fused_in_kernel_matches_reference(vs, golden_dir):
+    """VS_FLAG_ACT_NORM (ActNormWrapper fused into the step kernel) against steps of the reference's wrapper, and the
+    host-side wrapper on a single env object"""
+    L = vs._lib
+    g = np.load(os.path.join(golden_dir, "wrappers.npz"))
+    for name in ("qq-su", "qbb"):
+        tag = name.replace("-", "_")
+        n = g[f"{tag}_state"].shape[0]
+        env = vs.VecSimEnv(name, n, **KW[name])
+        env.set_act_norm(True)
+        env.reset(init_state=g[f"{tag}_state"].astype(np.float32))
+        if name == "qbb":
+            env.put(L.VS_HIDDEN, np.zeros((n, 2), dtype=np.float32))
+        env.step(torch.from_numpy(g[f"{tag}_act"].astype(np.float32)).cuda())
+        np.testing.assert_allclose(env.get(L.VS_STATE), g[f"{tag}_nstate"], rtol=1e-5, atol=2e-5)
+        np.testing.assert_allclose(env.get(L.VS_REW), g[f"{tag}_rew"], rtol=2e-4, atol=1e-12)
+        assert np.array_equal(env.get(L.VS_DONE).astype(bool), g[f"{tag}_done"])
+        # fused random policy: normalised actions in [-1, 1] are recorded, the env sees the de-normalised ones
+        env.reset(seed=1)
+        env.step_random(8, seed=2, record=True)
+        a = env.traj(8)["act"]
+        assert a.min() >= -1 and a.max() <= 1 and a.std() > 0.5
+    e = vs.QQubeSwingUpSim(**KW["qq-su"])
+    w = vs.ActNormWrapper(e)
+    w.reset(init_state=g["qq_su_state"][0].copy())
+    obs, rew, done, _ = w.step(g["qq_su_act"][0].copy())
+    np.testing.assert_allclose(obs, g["qq_su_obs"][0], rtol=1e-5, atol=1e-5)
+    assert rew == pytest.approx(g["qq_su_rew"][0], rel=2e-4, abs=1e-12)
+
+
+def test_param_buffer_on_device(vs, golden_dir):
+    """DomainRandWrapperBuffer on the device: lane i starts at set i mod B and walks the ring at its own resets (cyclic);
+    random selection only ever picks members of the buffer; the single-env wrapper follows the reference's order"""
+    L = vs._lib
+    g = np.load(os.path.join(golden_dir, "wrappers.npz"))
+    buf = g["omo_buffer"].astype(np.float32)
+    B, n = len(buf), 1000
+    env = vs.VecSimEnv("omo", n, **KW["omo"])
+    env.set_param_buffer([dict(mass=m, stiffness=k, damping=d) for m, k, d in buf], "cyclic")
+    env.set_auto_reset(True, seed=1)
+    env.reset(seed=2)
+    P = env.get(L.VS_PARAMS)
+    assert np.array_equal(P, buf[np.arange(n) % B])
+    env.step_random(400, seed=3)
+    cnt = env.get(L.VS_EPSTAT_COUNT).astype(np.int64)
+    assert cnt.min() >= 1
+    assert np.array_equal(env.get(L.VS_PARAMS), buf[(np.arange(n) + cnt) % B])  # one step along the ring per reset
+    K = env.get(L.VS_CONSTS)
+    np.testing.assert_allclose(K[:, 3], env.get(L.VS_PARAMS)[:, 1], rtol=1e-6)  # act bound = stiffness follows the params
+    env.set_param_buffer(buf, "random")
+    env.reset(seed=5)
+    P = env.get(L.VS_PARAMS)
+    idx = np.array([np.where((buf == p).all(axis=1))[0][0] for p in P])
+    assert np.bincount(idx, minlength=B).min() > n / B / 2
+    env.set_param_buffer(None)
+    # single env object: the reference's ring order
+    e = vs.OneMassOscillatorSim(**KW["omo"])
+    w = vs.DomainRandWrapperBuffer(e, None, selection="cyclic")
+    w.buffer = [dict(mass=float(m), stiffness=float(k), damping=float(d)) for m, k, d in g["omo_buffer"]]
+    w.ring_idx = 0
+    seq = []
+    for i in range(12):
+        w.reset()
+        seq.append([w.domain_param[k] for k in ("mass", "stiffness", "damping")])
+    np.testing.assert_allclose(np.array(seq), g["omo_buffer_seq"], rtol=1e-15)

@@ -291,3 +291,34 @@ def test_register_with_pyrado_when_the_reference_is_importable():
         for attr in ("float", "object"):
             if attr in np.__dict__:
                 delattr(np, attr)
+
+
+def test_domain_rand_wrapper_buffer_and_act_norm_host_side(golden_dir):
+    """DomainRandWrapperBuffer ring order and ActNormWrapper spaces / de-normalisation as in the reference
+    (environment_wrappers/test_domain_randomization.py:59-88)"""
+    g = np.load(os.path.join(golden_dir, "wrappers.npz"))
+    env = make("omo")
+    w = vs.DomainRandWrapperBuffer(env, None, selection="cyclic")
+    with pytest.raises(vs.TypeErr):
+        w.fill_buffer(3)  # no randomizer
+    w.buffer = [dict(mass=m, stiffness=k, damping=d) for m, k, d in g["omo_buffer"]]
+    w.ring_idx = 0
+    picked = []
+    for i in range(12):  # the reset itself needs the GPU; the ring logic does not
+        dp = w.buffer[w.ring_idx]
+        picked.append([dp["mass"], dp["stiffness"], dp["damping"]])
+        w._ring_idx = (w._ring_idx + 1) % len(w.buffer)
+    np.testing.assert_allclose(np.array(picked), g["omo_buffer_seq"], rtol=1e-15)
+    with pytest.raises(vs.ValueErr):
+        vs.DomainRandWrapperBuffer(env, None, selection="sometimes")
+    with pytest.raises(vs.ValueErr):
+        w.ring_idx = 99
+    rz = vs.create_default_randomizer(env)
+    w2 = vs.DomainRandWrapperBuffer(env, rz, selection="random")
+    w2.fill_buffer(4)
+    assert len(w2.buffer) == 4 and w2.ring_idx == 0 and set(w2.buffer[0]) == {"mass", "stiffness", "damping"}
+    an = vs.ActNormWrapper(make("qbb"))
+    assert np.array_equal(an.act_space.bound_lo, [-1, -1]) and np.array_equal(an.act_space.bound_up, [1, 1])
+    np.testing.assert_allclose(an._process_act(np.array([0.0, 1.0])), [0.0, 3.0])
+    np.testing.assert_allclose(an._process_act(np.array([-1.4, 0.5])), [-4.2, 1.5])
+    assert vs.inner_env(an).name == "qbb" and an.obs_space == vs.inner_env(an).obs_space

@@ -180,3 +180,16 @@ def test_nominal_params_match_reference(golden_dir):
         nominal = cls.nominal_params(1, long=False)[0] if name == "qcp-st" else cls.nominal_params(1)[0]
         for k, v in zip(cls.param_names, nominal):
             assert nom[k] == pytest.approx(v, rel=1e-15, abs=0)
+
+
+def test_act_norm_wrapper_golden(golden_dir):
+    """the oracle's act_norm flag against steps of the reference's ActNormWrapper (action_normalization.py:63-89)"""
+    g = np.load(os.path.join(golden_dir, "wrappers.npz"))
+    for name in ("qq-su", "qbb"):
+        tag = name.replace("-", "_")
+        ref = cpu_ref.make_ref(name, **KW[name], act_norm=True)
+        n = g[f"{tag}_state"].shape[0]
+        out = ref.step(g[f"{tag}_state"], np.zeros((n, ref.H)), g[f"{tag}_act"], ref.nominal_params(n), np.zeros(n, dtype=int))
+        np.testing.assert_allclose(out["state"], g[f"{tag}_nstate"], rtol=RTOL, atol=ATOL)
+        np.testing.assert_allclose(out["rew"], g[f"{tag}_rew"], rtol=1e-10)
+        assert np.array_equal(out["done"], g[f"{tag}_done"])
