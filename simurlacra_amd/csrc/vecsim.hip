@@ -88,12 +88,18 @@ template <class E>
 __device__ __forceinline__ StepOut step_one(const Task& T, const float* c, float* s, float* h, const float* a_raw,
                                             int& step, bool& yielded, const float* ob) {
     StepOut o;
+    // ActNormWrapper._process_act (action_normalization.py:66-72), branch-free: a wave-uniform select keeps the step one
+    // basic block for the scheduler
     float an[E::A];
-    if (T.flags & VS_FLAG_ACT_NORM) {  // ActNormWrapper._process_act (action_normalization.py:66-72)
+    {
+        const bool nrm = (T.flags & VS_FLAG_ACT_NORM) != 0;
         float lb[E::A], ub[E::A];
         E::act_bounds(c, lb, ub);
 #pragma unroll
-        for (int j = 0; j < E::A; ++j) an[j] = lb[j] + (a_raw[j] + 1.0f) * (ub[j] - lb[j]) / 2.0f;
+        for (int j = 0; j < E::A; ++j) {
+            float m = lb[j] + (a_raw[j] + 1.0f) * (ub[j] - lb[j]) * 0.5f;
+            an[j] = nrm ? m : a_raw[j];
+        }
         a_raw = an;
     }
 #ifdef VS_ABLATE_REWARD  // diagnostic builds only (profiling by ablation); never defined in the shipped library
