@@ -56,19 +56,19 @@ struct Dev {
 // ---------------------------------------------------------------------------------------------------- reward / step
 // DesStateTask.step_rew / RadiallySymmDesStateTask.step_rew + the three reward functions
 // (P/tasks/desired_state.py:107-110,146-155; P/tasks/reward_functions.py:212-221,237-244,276-282)
-template <class E>
-__device__ __forceinline__ float step_reward(const Task& T, const float* c, const float* s, const float* a_raw) {
-    float cost = 0.f;
+template <class E, class R>
+__device__ __forceinline__ R step_reward(const Task& T, const float* c, const R* s, const R* a_raw) {
+    R cost = 0.f;
 #pragma unroll
     for (int j = 0; j < E::S; ++j) {
-        float e = T.des[j] - s[j];
+        R e = T.des[j] - s[j];
         if (E::RADIAL >= 0) {
             if (j == E::RADIAL) e = fmod_2pi(e);
             e = fold_pi(e);  // all dims (Q4)
         }
         cost += e * (T.qd[j] * e);
     }
-    float ca = 0.f;
+    R ca = 0.f;
 #pragma unroll
     for (int j = 0; j < E::A; ++j) ca += a_raw[j] * (T.rd[j] * a_raw[j]);  // err_a = -act
     cost += ca;
@@ -77,41 +77,44 @@ __device__ __forceinline__ float step_reward(const Task& T, const float* c, cons
     return exp_neg_fast(-c[E::CMAX >= 0 ? E::CMAX : 0] * cost);
 }
 
-struct StepOut {
-    float rew;
+template <class R>
+struct StepOutT {
+    R rew;
     bool done, failed, err;
 };
+using StepOut = StepOutT<float>;
 
 // SimPyEnv.step for one lane (P/environments/pysim/base.py:217-241); s, h, step, yielded are updated in place.
 // ob: observe() of the pre-step state if the caller holds it in registers (saves the trig it shares with the dynamics)
-template <class E>
-__device__ __forceinline__ StepOut step_one(const Task& T, const float* c, float* s, float* h, const float* a_raw,
-                                            int& step, bool& yielded, const float* ob) {
-    StepOut o;
+template <class E, class R>
+__device__ __forceinline__ StepOutT<R> step_one(const Task& T, const float* c, R* s, R* h, const R* a_raw, int& step,
+                                                bool& yielded, const R* ob) {
+    StepOutT<R> o;
     // ActNormWrapper._process_act (action_normalization.py:66-72), branch-free: a wave-uniform select keeps the step one
     // basic block for the scheduler
-    float an[E::A];
+    R an[E::A];
     {
         const bool nrm = (T.flags & VS_FLAG_ACT_NORM) != 0;
         float lb[E::A], ub[E::A];
         E::act_bounds(c, lb, ub);
 #pragma unroll
         for (int j = 0; j < E::A; ++j) {
-            float m = lb[j] + (a_raw[j] + 1.0f) * (ub[j] - lb[j]) * 0.5f;
-            an[j] = nrm ? m : a_raw[j];
+            R m = lb[j] + (a_raw[j] + 1.0f) * (ub[j] - lb[j]) * 0.5f;
+            an[j] = vsel(nrm, m, a_raw[j]);
         }
         a_raw = an;
     }
 #ifdef VS_ABLATE_REWARD  // diagnostic builds only (profiling by ablation); never defined in the shipped library
     o.rew = a_raw[0];
 #else
-    o.rew = step_reward<E>(T, c, s, a_raw);  // pre-step state, unclipped action (Q3)
+    o.rew = step_reward<E, R>(T, c, s, a_raw);  // pre-step state, unclipped action (Q3)
 #endif
-    float alo[E::A], ahi[E::A], a[E::A];
+    float alo[E::A], ahi[E::A];
+    R a[E::A];
     E::act_bounds(c, alo, ahi);
     o.err = false;
 #pragma unroll
-    for (int j = 0; j < E::A; ++j) o.err |= isnan(a_raw[j]);
+    for (int j = 0; j < E::A; ++j) o.err |= visnan(a_raw[j]);
     E::limit_act(c, alo, ahi, a_raw, a);  // Env.limit_act -> act_space.project_to
 #ifdef VS_ABLATE_DYNAMICS
     s[0] += a[0] * 1e-6f;
@@ -124,10 +127,11 @@ __device__ __forceinline__ StepOut step_one(const Task& T, const float* c, float
     o.failed = false;
 #pragma unroll
     for (int j = 0; j < E::S; ++j) {
-        o.err |= isnan(s[j]);
-        // not state_space.contains(s') (Q9, Q10): s < lo or s > hi; every state box of the five envs is symmetric
-        // (lo == -hi), so this is |s| > hi -- one compare with the abs modifier, NaN compares false as in NumPy
-        o.failed |= E::SYMMETRIC_BOX ? (fabsf(s[j]) > shi[j]) : ((s[j] < slo[j]) | (s[j] > shi[j]));
+        float sv = val(s[j]);
+        o.err |= isnan(sv);
+        // not state_space.contains(s') (Q9, Q10): s < lo or s > hi; most state boxes are symmetric (lo == -hi), so this
+        // is |s| > hi -- one compare with the abs modifier, NaN compares false as in NumPy
+        o.failed |= E::SYMMETRIC_BOX ? (fabsf(sv) > shi[j]) : ((sv < slo[j]) | (sv > shi[j]));
     }
     o.done = o.failed | (step >= T.max_steps);
     if (E::FINAL != FINAL_NONE) {
@@ -135,15 +139,15 @@ __device__ __forceinline__ StepOut step_one(const Task& T, const float* c, float
         if (o.done && !yielded) {
             if (o.failed) {
                 if (E::FINAL == FINAL_CONST_MALUS) {
-                    o.rew += -1000.0f;  // always_negative, factor 1e3 (:165-174)
+                    o.rew += -1000.0f;  // always_negative, factor 1e3 (:165-174)  [R += float]
                 } else {
                     // state- and time-dependent (:215-226): -remaining_steps * |step_rew(s', act = 0)|, remaining_steps as
                     // computed before the step (pysim/base.py:219); 0 for max_steps = inf
-                    float zero[E::A];
+                    R zero[E::A];
 #pragma unroll
                     for (int j = 0; j < E::A; ++j) zero[j] = 0.f;
                     float remaining = T.max_steps == INT_MAX ? 0.f : (float)(T.max_steps - step);
-                    o.rew += -1.0f * remaining * fabsf(step_reward<E>(T, c, s, zero));
+                    o.rew += -1.0f * remaining * vabs(step_reward<E, R>(T, c, s, zero));
                 }
             }
             yielded = true;
@@ -284,7 +288,7 @@ __device__ __forceinline__ void step_body(const Task& T, const Dev& d, const flo
     int step = d.step[i];
     bool yielded = E::FINAL != FINAL_NONE ? d.yielded[i] != 0 : false;
 
-    StepOut o = step_one<E>(T, c, s, h, a, step, yielded, nullptr);
+    StepOut o = step_one<E, float>(T, c, s, h, a, step, yielded, (const float*)nullptr);
 
     float ret = d.ret[i] + o.rew;
     d.rew[i] = o.rew;
@@ -385,7 +389,7 @@ __device__ __forceinline__ void rollout_body(const Task& T, const Dev& d, int k_
             for (int j = 0; j < E::A; ++j) d.traj_act[(tb * E::A + j) * ld + i] = a[j];
         }
         if (!frozen) {
-            StepOut o = step_one<E>(T, c, s, h, a, step, yielded, REC ? ob : nullptr);
+            StepOut o = step_one<E, float>(T, c, s, h, a, step, yielded, REC ? (const float*)ob : (const float*)nullptr);
             rew = o.rew;
             done = o.done;
             failed = o.failed;

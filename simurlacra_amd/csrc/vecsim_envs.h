@@ -10,6 +10,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "vecsim_dual.h"
+
 namespace vs {
 
 constexpr int MAXS = 8, MAXA = 2, MAXO = 8, MAXH = 2, MAXP = 20, MAXK = 20;
@@ -58,16 +60,31 @@ __device__ __forceinline__ float fmod_2pi(float e) {
 // the two sequential +-pi folds of RadiallySymmDesStateTask.step_rew (P/tasks/desired_state.py:152-153, Q4)
 // e > pi  <=>  2pi - e < e  and  e < -pi  <=>  -2pi - e > e, so each fold is a min / max with the reflected value
 // (identical results for every non-NaN e, ties included; a NaN state is reported through the error flag).
-__device__ __forceinline__ float fold_pi(float e) {
-    e = fminf(e, TWO_PI_F - e);
-    e = fmaxf(e, -TWO_PI_F - e);
+template <class R>
+__device__ __forceinline__ R fold_pi(R e) {
+    e = vmin(e, TWO_PI_F - e);
+    e = vmax(e, -TWO_PI_F - e);
     return e;
+}
+template <int N>
+__device__ __forceinline__ Dual<N> fmod_2pi(const Dual<N>& e) {  // slope 1 everywhere it is differentiable
+    Dual<N> r = e;
+    r.v = fmod_2pi(e.v);
+    return r;
 }
 
 // exp(x) for x <= 0 on the reward path: v_exp_f32 on x*log2(e).  Rewards below fp32's normal range flush to 0 either way
 // (cost > 87); above that the rounding of x*log2(e) costs <= 5e-6 relative -- inside the 2e-4 reward tolerance, and
 // 2 instructions instead of the library's ~14.
 __device__ __forceinline__ float exp_neg_fast(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+template <int N>
+__device__ __forceinline__ Dual<N> exp_neg_fast(const Dual<N>& x) {
+    Dual<N> r;
+    r.v = exp_neg_fast(x.v);
+#pragma unroll
+    for (int k = 0; k < N; ++k) r.d[k] = r.v * x.d[k];
+    return r;
+}
 
 // sin and cos of a BOUNDED angle (every angle on the hot path is a state inside / next to its box, |x| < ~1e3):
 // 3-term Cody-Waite reduction by pi/2 with FMAs (exact products), then the Cephes minimax polynomials on [-pi/4, pi/4].
@@ -98,6 +115,27 @@ __device__ __forceinline__ void sincos_fast(float x, float* sn, float* cs) {
 __device__ __forceinline__ float rcp_fast(float x) {
     float r = __builtin_amdgcn_rcpf(x);
     return fmaf(fmaf(-x, r, 1.0f), r, r);
+}
+
+template <int N>
+__device__ __forceinline__ void sincos_fast(const Dual<N>& x, Dual<N>* sn, Dual<N>* cs) {
+    float sv, cv;
+    sincos_fast(x.v, &sv, &cv);
+    sn->v = sv;
+    cs->v = cv;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        sn->d[k] = cv * x.d[k];
+        cs->d[k] = -sv * x.d[k];
+    }
+}
+template <int N>
+__device__ __forceinline__ Dual<N> rcp_fast(const Dual<N>& x) {
+    Dual<N> r;
+    r.v = rcp_fast(x.v);
+#pragma unroll
+    for (int k = 0; k < N; ++k) r.d[k] = -r.v * r.v * x.d[k];
+    return r;
 }
 
 __device__ __forceinline__ float sgnf(float x) { return (float)(x > 0.f) - (float)(x < 0.f); }  // np.sign
@@ -159,11 +197,12 @@ struct EnvDefaults {
     static constexpr bool SYMMETRIC_BOX = true;  // state box lo == -hi
     static constexpr int FINAL = FINAL_NONE;
     // Env.limit_act -> BoxSpace.project_to (P/spaces/box.py:180-184); np.clip propagates NaN (fminf/fmaxf would drop it)
-    __device__ static void limit_act(const float*, const float* lo, const float* hi, const float* a_raw, float* a) {
+    template <class R>
+    __device__ static void limit_act(const float*, const float* lo, const float* hi, const R* a_raw, R* a) {
 #pragma unroll
         for (int j = 0; j < A_; ++j) {
-            a[j] = fminf(fmaxf(a_raw[j], lo[j]), hi[j]);
-            if (isnan(a_raw[j])) a[j] = a_raw[j];
+            a[j] = vmin(vmax(a_raw[j], lo[j]), hi[j]);
+            if (visnan(a_raw[j])) a[j] = a_raw[j];
         }
     }
     // DummyPolicy: act_space.sample_uniform() (P/policies/feed_forward/dummy.py:77-84)
@@ -190,13 +229,15 @@ struct Omo : EnvDefaults<1> {
         hi[0] = 1.0f; hi[1] = 10.0f; lo[0] = -1.0f; lo[1] = -10.0f;
     }
     __device__ static void act_bounds(const float* c, float* lo, float* hi) { hi[0] = c[C_AMAX]; lo[0] = -c[C_AMAX]; }
-    __device__ static void dynamics(const Task& T, const float* c, float* s, float*, const float* a, const float*) {  // :105-114
-        float sd0 = s[1];
-        float sd1 = c[C_A10] * s[0] + c[C_A11] * s[1] + c[C_B1] * a[0];
+    template <class R>
+    __device__ static void dynamics(const Task& T, const float* c, R* s, R*, const R* a, const R*) {  // :105-114
+        R sd0 = s[1];
+        R sd1 = c[C_A10] * s[0] + c[C_A11] * s[1] + c[C_B1] * a[0];
         s[0] = s[0] + sd0 * T.dt;  // forward Euler
         s[1] = s[1] + sd1 * T.dt;
     }
-    __device__ static void observe(const float* s, float* o) { o[0] = s[0]; o[1] = s[1]; }
+    template <class R>
+    __device__ static void observe(const R* s, R* o) { o[0] = s[0]; o[1] = s[1]; }
     __device__ static void sample_init(const Task&, const float*, Rng& g, float* init) {  // :59-60, box.py:169-178
         init[0] = g.uniform(-0.75f, -0.65f);
         init[1] = g.uniform(-0.1f, 0.1f);
@@ -214,9 +255,10 @@ struct BobT : EnvDefaults<1> {
     static constexpr int REW = REW_SCALED_EXP, RADIAL = -1;
     // DiscreteSpace.project_to (P/spaces/discrete.py:104-131): an action that is np.isclose to one of the elements is
     // kept as it is, anything else snaps to the closest element (argmin: the first of two equally close ones)
-    __device__ static void limit_act(const float* c, const float* lo, const float* hi, const float* a_raw, float* a) {
+    template <class R>
+    __device__ static void limit_act(const float* c, const float* lo, const float* hi, const R* a_raw, R* a) {
         if (V == 0) { EnvDefaults<1>::limit_act(c, lo, hi, a_raw, a); return; }
-        float x = a_raw[0];
+        float x = val(a_raw[0]);
         float e[3] = {lo[0], (lo[0] + hi[0]) * 0.5f, hi[0]};
         float tol = 1e-8f + 1e-5f * fabsf(x);  // np.isclose(eles, cand): atol + rtol * |cand|
         bool close = false;
@@ -228,8 +270,7 @@ struct BobT : EnvDefaults<1> {
             close |= dk <= tol;
             if (dk < bd) { bd = dk; best = k; }
         }
-        a[0] = close ? x : e[best];
-        if (isnan(x)) a[0] = x;
+        a[0] = vsel(close || isnan(x), a_raw[0], R(e[best]));
     }
     __device__ static float sample_action(const float* c, float lo, float hi, float u01, int) {
         if (V == 0) return lo + (hi - lo) * u01;
@@ -261,19 +302,21 @@ struct BobT : EnvDefaults<1> {
         for (int j = 0; j < 4; ++j) lo[j] = -hi[j];
     }
     __device__ static void act_bounds(const float* c, float* lo, float* hi) { hi[0] = c[C_AMAX]; lo[0] = -c[C_AMAX]; }
-    __device__ static void dynamics(const Task& T, const float* c, float* s, float*, const float* act, const float*) {  // :110-129
-        float x = s[0], a = s[1] + c[C_OFF], x_dot = s[2], a_dot = s[3];
-        float sa, ca;
+    template <class R>
+    __device__ static void dynamics(const Task& T, const float* c, R* s, R*, const R* act, const R*) {  // :110-129
+        R x = s[0], a = s[1] + c[C_OFF], x_dot = s[2], a_dot = s[3];
+        R sa, ca;
         sincos_fast(a, &sa, &ca);
-        float zeta_beam = c[C_M] * x * x + c[C_J_BEAM];
-        float x_ddot = (-c[C_FRICT] * x_dot + c[C_M] * x * a_dot * a_dot - c[C_MG] * sa) * c[C_INV_ZETA_BALL];
-        float a_ddot = (act[0] - 2.0f * c[C_M] * x * x_dot * a_dot - c[C_MG] * ca * x) * rcp_fast(zeta_beam);
+        R zeta_beam = c[C_M] * x * x + c[C_J_BEAM];
+        R x_ddot = (-c[C_FRICT] * x_dot + c[C_M] * x * a_dot * a_dot - c[C_MG] * sa) * c[C_INV_ZETA_BALL];
+        R a_ddot = (act[0] - 2.0f * c[C_M] * x * x_dot * a_dot - c[C_MG] * ca * x) * rcp_fast(zeta_beam);
         s[2] += x_ddot * T.dt;  // symplectic Euler: velocity first
         s[3] += a_ddot * T.dt;
         s[0] += s[2] * T.dt;
         s[1] += s[3] * T.dt;
     }
-    __device__ static void observe(const float* s, float* o) {
+    template <class R>
+    __device__ static void observe(const R* s, R* o) {
         for (int j = 0; j < 4; ++j) o[j] = s[j];
     }
     __device__ static void sample_init(const Task&, const float* c, Rng& g, float* init) {  // :60-73, compound.py:84-87
@@ -319,37 +362,39 @@ struct QQT : EnvDefaults<1> {
     }
     __device__ static void act_bounds(const float*, float* lo, float* hi) { hi[0] = 4.5f; lo[0] = -4.5f; }  // MAX_ACT_QQ
     // ob: observation of the PRE-step state when the caller has it in registers (fused rollout), else nullptr
-    __device__ static void dynamics(const Task& T, const float* c, float* s, float*, const float* act, const float* ob) {
+    template <class R>
+    __device__ static void dynamics(const Task& T, const float* c, R* s, R*, const R* act, const R* ob) {
         // dead zone, _step_dynamics :130-131
-        float u = act[0];
+        R u = act[0];
         if (c[C_TH_NEG] <= u && u <= c[C_TH_POS]) u = 0.f;
         // _dyn :89-125, evaluated once: the reference's "RK4" re-evaluates _dyn at self.state in every stage (Q1), so
         // k_j differ only in their position-derivative slots and the update collapses to
         //   v' = v + dt a,  p' = p + dt v + dt^2/2 a        (closed form verified against the oracle: max abs diff 0)
-        float thd = s[2], ald = s[3];
-        float sin_al, cos_al;
+        R thd = s[2], ald = s[3];
+        R sin_al, cos_al;
         if (ob) { sin_al = ob[2]; cos_al = ob[3]; }  // observe() already holds sin/cos(alpha) of this state
         else sincos_fast(s[1], &sin_al, &cos_al);
-        float sin_2al = 2.0f * sin_al * cos_al;
-        float a = c[C_C0] + c[C_C1] * sin_al * sin_al;
-        float b = c[C_C2] * cos_al;
-        float cc = c[C_C3];
-        float det = a * cc - b * b;
-        float trq = c[C_KM] * (u - c[C_KM] * thd) * c[C_RM];  // C_RM holds 1 / Rm
-        float c0 = c[C_C1] * sin_2al * thd * ald - c[C_C2] * sin_al * ald * ald;
-        float c1 = -0.5f * c[C_C1] * sin_2al * thd * thd + c[C_C4] * sin_al;
-        float x = trq - c[C_DR] * thd - c0;
-        float y = -c[C_DP] * ald - c1;
-        float inv_det = rcp_fast(det);
-        float thdd = (cc * x - b * y) * inv_det;
-        float aldd = (a * y - b * x) * inv_det;
-        float dt = T.dt, hdt2 = 0.5f * dt * dt;
+        R sin_2al = 2.0f * sin_al * cos_al;
+        R a = c[C_C0] + c[C_C1] * sin_al * sin_al;
+        R b = c[C_C2] * cos_al;
+        R cc = c[C_C3];
+        R det = a * cc - b * b;
+        R trq = c[C_KM] * (u - c[C_KM] * thd) * c[C_RM];  // C_RM holds 1 / Rm
+        R c0 = c[C_C1] * sin_2al * thd * ald - c[C_C2] * sin_al * ald * ald;
+        R c1 = -0.5f * c[C_C1] * sin_2al * thd * thd + c[C_C4] * sin_al;
+        R x = trq - c[C_DR] * thd - c0;
+        R y = -c[C_DP] * ald - c1;
+        R inv_det = rcp_fast(det);
+        R thdd = (cc * x - b * y) * inv_det;
+        R aldd = (a * y - b * x) * inv_det;
+        R dt = T.dt, hdt2 = 0.5f * dt * dt;
         s[0] = s[0] + dt * thd + hdt2 * thdd;
         s[1] = s[1] + dt * ald + hdt2 * aldd;
         s[2] = thd + dt * thdd;
         s[3] = ald + dt * aldd;
     }
-    __device__ static void observe(const float* s, float* o) {  // :148-149
+    template <class R>
+    __device__ static void observe(const R* s, R* o) {  // :148-149
         sincos_fast(s[0], &o[0], &o[1]);
         sincos_fast(s[1], &o[2], &o[3]);
         o[4] = s[2];
@@ -423,50 +468,52 @@ struct QcpT : EnvDefaults<1> {
     }
     __device__ static void act_bounds(const float*, float* lo, float* hi) { hi[0] = 6.0f; lo[0] = -6.0f; }  // MAX_ACT_QCP
     // one evaluation of QCartPoleSim._dynamics (:166-230) on the augmented state y = [x, th, x_dot, th_dot], action u
-    __device__ static void f_dyn(const Task& T, const float* c, const float* y, float u, float thdd_prev, float* k,
-                                 float& thdd_out, const float* ob) {
-        float th = y[1], x_dot = y[2], th_dot = y[3];
-        float sin_th, cos_th;
+    template <class R>
+    __device__ static void f_dyn(const Task& T, const float* c, const R* y, R u, R thdd_prev, R* k, R& thdd_out, const R* ob) {
+        R th = y[1], x_dot = y[2], th_dot = y[3];
+        R sin_th, cos_th;
         if (ob) { sin_th = ob[1]; cos_th = ob[2]; }
         else sincos_fast(th, &sin_th, &cos_th);
         bool simple = (T.flags & 1) != 0;
         if (!simple && c[C_TH_NEG] <= u && u <= c[C_TH_POS]) u = 0.f;  // dead zone :188-192
-        float f_act = c[C_KA] * (c[C_ETA_M] * u - c[C_KB] * x_dot);
-        float f_tot = f_act;
+        R f_act = c[C_KA] * (c[C_ETA_M] * u - c[C_KB] * x_dot);
+        R f_tot = f_act;
         if (!simple) {
-            float f_normal = c[C_MTG] - c[C_MPL2] * (sin_th * thdd_prev + cos_th * th_dot * th_dot);
-            float f_c = f_normal < 0.f ? 0.f : c[C_MU] * f_normal * sgnf(x_dot);
+            R f_normal = c[C_MTG] - c[C_MPL2] * (sin_th * thdd_prev + cos_th * th_dot * th_dot);
+            R f_c = vsel(f_normal < 0.f, R(0.f), c[C_MU] * f_normal * sgnf(val(x_dot)));
             f_tot = f_act - f_c;
         }
-        float M01 = c[C_MPL] * cos_th;
-        float r0 = f_tot - c[C_BEQ] * x_dot - c[C_MPL] * sin_th * th_dot * th_dot;
-        float r1 = -c[C_BP] * th_dot - c[C_MPLG] * sin_th;
+        R M01 = c[C_MPL] * cos_th;
+        R r0 = f_tot - c[C_BEQ] * x_dot - c[C_MPL] * sin_th * th_dot * th_dot;
+        R r1 = -c[C_BP] * th_dot - c[C_MPLG] * sin_th;
         // np.linalg.solve on the SPD 2x2 -> closed form
-        float inv_det = rcp_fast(c[C_M00] * c[C_M11] - M01 * M01);
-        float x_ddot = (c[C_M11] * r0 - M01 * r1) * inv_det;
-        float th_ddot = (c[C_M00] * r1 - M01 * r0) * inv_det;
+        R inv_det = rcp_fast(c[C_M00] * c[C_M11] - M01 * M01);
+        R x_ddot = (c[C_M11] * r0 - M01 * r1) * inv_det;
+        R th_ddot = (c[C_M00] * r1 - M01 * r0) * inv_det;
         k[0] = x_dot + x_ddot * T.dt;  // already Euler-advanced velocities as position derivative (Q6, :227-230)
         k[1] = th_dot + th_ddot * T.dt;
         k[2] = x_ddot;
         k[3] = th_ddot;
         thdd_out = th_ddot;
     }
-    __device__ static void dynamics(const Task& T, const float* c, float* s, float* h, const float* act, const float* ob) {
+    template <class R>
+    __device__ static void dynamics(const Task& T, const float* c, R* s, R* h, const R* act, const R* ob) {
         // rk4 (:591-655) over [x, th, x_dot, th_dot, u]; u has zero derivative; th_ddot chained through the stages.
         // The four stage vectors live in VGPRs (16 floats per lane): there is no cross-lane reuse to stage in LDS.
-        float u = act[0], dt = T.dt, dt2 = dt / 2.0f;
-        float k1[4], k2[4], k3[4], k4[4], y[4], a1, a2, a3, a4;
+        R u = act[0], dt = T.dt, dt2 = dt / 2.0f;
+        R k1[4], k2[4], k3[4], k4[4], y[4], a1, a2, a3, a4;
         f_dyn(T, c, s, u, h[0], k1, a1, ob);
         for (int j = 0; j < 4; ++j) y[j] = s[j] + dt2 * k1[j];
-        f_dyn(T, c, y, u, a1, k2, a2, nullptr);
+        f_dyn(T, c, y, u, a1, k2, a2, (const R*)nullptr);
         for (int j = 0; j < 4; ++j) y[j] = s[j] + dt2 * k2[j];
-        f_dyn(T, c, y, u, a2, k3, a3, nullptr);
+        f_dyn(T, c, y, u, a2, k3, a3, (const R*)nullptr);
         for (int j = 0; j < 4; ++j) y[j] = s[j] + dt * k3[j];
-        f_dyn(T, c, y, u, a3, k4, a4, nullptr);
+        f_dyn(T, c, y, u, a3, k4, a4, (const R*)nullptr);
         for (int j = 0; j < 4; ++j) s[j] = s[j] + dt / 6.0f * (k1[j] + 2.0f * k2[j] + 2.0f * k3[j] + k4[j]);
         h[0] = (a1 + a2 + a3 + a4) / 4.0f;  // mean of the stage th_ddots (:652)
     }
-    __device__ static void observe(const float* s, float* o) {  // :107-108
+    template <class R>
+    __device__ static void observe(const R* s, R* o) {  // :107-108
         o[0] = s[0];
         sincos_fast(s[1], &o[1], &o[2]);
         o[3] = s[2];
@@ -514,15 +561,17 @@ struct Pend : EnvDefaults<1> {
         hi[0] = PI4_F; hi[1] = PI4_F; lo[0] = -PI4_F; lo[1] = -PI4_F;
     }
     __device__ static void act_bounds(const float* c, float* lo, float* hi) { hi[0] = c[C_AMAX]; lo[0] = -c[C_AMAX]; }
-    __device__ static void dynamics(const Task& T, const float* c, float* s, float*, const float* act, const float* ob) {
-        float sn, cs;
+    template <class R>
+    __device__ static void dynamics(const Task& T, const float* c, R* s, R*, const R* act, const R* ob) {
+        R sn, cs;
         if (ob) sn = ob[0];
         else sincos_fast(s[0], &sn, &cs);
-        float th_ddot = (act[0] - c[C_MGL2] * sn - c[C_DAMP] * s[1]) * c[C_INV_J];  // :103-106
+        R th_ddot = (act[0] - c[C_MGL2] * sn - c[C_DAMP] * s[1]) * c[C_INV_J];  // :103-106
         s[1] += th_ddot * T.dt;  // symplectic Euler :109-110
         s[0] += s[1] * T.dt;
     }
-    __device__ static void observe(const float* s, float* o) {  // :91-92
+    template <class R>
+    __device__ static void observe(const R* s, R* o) {  // :91-92
         sincos_fast(s[0], &o[0], &o[1]);
         o[2] = s[1];
     }
@@ -605,42 +654,44 @@ struct Qbb : EnvDefaults<2> {
     __device__ static void act_bounds(const float*, float* lo, float* hi) {
         hi[0] = hi[1] = 3.0f; lo[0] = lo[1] = -3.0f;  // MAX_ACT_QBB
     }
-    __device__ static void dynamics(const Task& T, const float* c, float* s, float* h, const float* act, const float*) {  // :247-330
+    template <class R>
+    __device__ static void dynamics(const Task& T, const float* c, R* s, R* h, const R* act, const R*) {  // :247-330
         bool simple = (T.flags & 1) != 0;
-        float a0 = act[0], a1 = act[1];
+        R a0 = act[0], a1 = act[1];
         if (!simple && c[C_TXN] <= a0 && a0 <= c[C_TXP]) a0 = 0.f;  // dead zones :261-264
         if (!simple && c[C_TYN] <= a1 && a1 <= c[C_TYP]) a1 = 0.f;
-        float th_x = s[0] + c[C_OFFX], th_y = s[1] + c[C_OFFY];
-        float x = s[2], y = s[3], th_x_dot = s[4], th_y_dot = s[5], x_dot = s[6], y_dot = s[7];
-        float th_x_ddot = (c[C_AM] * a0 - c[C_BEQV] * th_x_dot) * c[C_JEQ];  // C_JEQ holds 1 / J_eq
-        float th_y_ddot = (c[C_AM] * a1 - c[C_BEQV] * th_y_dot) * c[C_JEQ];
-        float sx, cx, sy, cy, sa, ca, sb, cb;
+        R th_x = s[0] + c[C_OFFX], th_y = s[1] + c[C_OFFY];
+        R x = s[2], y = s[3], th_x_dot = s[4], th_y_dot = s[5], x_dot = s[6], y_dot = s[7];
+        R th_x_ddot = (c[C_AM] * a0 - c[C_BEQV] * th_x_dot) * c[C_JEQ];  // C_JEQ holds 1 / J_eq
+        R th_y_ddot = (c[C_AM] * a1 - c[C_BEQV] * th_y_dot) * c[C_JEQ];
+        R sx, cx, sy, cy, sa, ca, sb, cb;
         sincos_fast(th_x, &sx, &cx);
         sincos_fast(th_y, &sy, &cy);
         sincos_fast(h[0], &sa, &ca);
         sincos_fast(h[1], &sb, &cb);
-        float ck = c[C_CKIN];
-        float inv_ca = rcp_fast(ca), inv_cb = rcp_fast(cb);
-        float a_dot = ck * th_x_dot * cx * inv_ca;
-        float b_dot = ck * -th_y_dot * cy * inv_cb;  // cos(-th_y) = cos(th_y)
-        float x_ddot, y_ddot;
+        R ck = c[C_CKIN];
+        R inv_ca = rcp_fast(ca), inv_cb = rcp_fast(cb);
+        R a_dot = ck * th_x_dot * cx * inv_ca;
+        R b_dot = ck * -th_y_dot * cy * inv_cb;  // cos(-th_y) = cos(th_y)
+        R x_ddot, y_ddot;
         if (simple) {
             x_ddot = c[C_CKMGR2] * sx * c[C_ZETA];  // C_ZETA holds 1 / zeta
             y_ddot = c[C_CKMGR2] * sy * c[C_ZETA];
         } else {
-            float a_ddot = inv_ca * (ck * (th_x_ddot * cx - th_x_dot * th_x_dot * sx) + a_dot * a_dot * sa);
+            R a_ddot = inv_ca * (ck * (th_x_ddot * cx - th_x_dot * th_x_dot * sx) + a_dot * a_dot * sa);
             // -(-th_y_dot)^2 * sin(-th_y) = + th_y_dot^2 * sin(th_y)
-            float b_ddot = inv_cb * (ck * (-th_y_ddot * cy + th_y_dot * th_y_dot * sy) + b_dot * b_dot * sb);
+            R b_ddot = inv_cb * (ck * (-th_y_ddot * cy + th_y_dot * th_y_dot * sy) + b_dot * b_dot * sb);
             x_ddot = (-c[C_BDR2] * x_dot - c[C_JBR] * a_ddot + c[C_MR2] * x * a_dot * a_dot + c[C_CKMGR2] * sx) * c[C_ZETA];
             y_ddot = (-c[C_BDR2] * y_dot - c[C_JBR] * b_ddot + c[C_MR2] * y * b_dot * b_dot + c[C_CKMGR2] * sy) * c[C_ZETA];
         }
-        float dt = T.dt;
+        R dt = T.dt;
         s[4] += th_x_ddot * dt; s[5] += th_y_ddot * dt; s[6] += x_ddot * dt; s[7] += y_ddot * dt;  // symplectic Euler
         s[0] += s[4] * dt; s[1] += s[5] * dt; s[2] += s[6] * dt; s[3] += s[7] * dt;
         h[0] += a_dot * dt;  // forward Euler on the plate angles :330
         h[1] += b_dot * dt;
     }
-    __device__ static void observe(const float* s, float* o) {
+    template <class R>
+    __device__ static void observe(const R* s, R* o) {
         for (int j = 0; j < 8; ++j) o[j] = s[j];
     }
     __device__ static void sample_init(const Task&, const float* c, Rng& g, float* init) {  // :108-117, polar.py:108-113
