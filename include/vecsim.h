@@ -72,7 +72,10 @@ enum vs_buffer {
     VS_EPSTAT_COUNT = 19,  /* u32 [ld]  completed episodes per env since vs_clear_episodes */
     VS_EPSTAT_RETSUM = 20, /* f32 [ld]  sum of their undiscounted returns */
     VS_EPSTAT_LENSUM = 21, /* i32 [ld]  sum of their lengths */
-    VS_BUFFER_COUNT = 22
+    VS_JAC_STATE = 22,     /* f32 [S][S+A][ld]  d s'_j / d (s, a)_k of the last vs_step_jac */
+    VS_JAC_REW = 23,       /* f32 [S+A][ld]     d r / d (s, a)_k */
+    VS_JAC_OBS = 24,       /* f32 [O][S+A][ld]  d obs'_j / d (s, a)_k */
+    VS_BUFFER_COUNT = 25
 };
 
 /* vs_task_cfg.flags */
@@ -178,6 +181,11 @@ int vs_set_auto_reset(vs_handle h, int on, uint64_t seed);
 /* actions: device f32, element (env i, dim j) at actions[i * env_stride + j * dim_stride]
  * ([A][ld] SoA: env_stride 1, dim_stride ld;  [N][A] row-major policy output: env_stride A, dim_stride 1) */
 int vs_step(vs_handle h, const float* actions, int64_t env_stride, int64_t dim_stride);
+/* vs_step plus the step Jacobians d(s', r, obs') / d(s, a) (forward-mode differentiation of the same step code): what the
+ * fork computes with torch autograd for its SAC-with-gradients (P/sampling/rollout.py:836-837 around
+ * quanser_cartpole.py:233-431), for every family.  The raw action is the differentiation variable (a clipped or dead-zoned
+ * action has zero gradient); hidden state is held constant; auto-reset must be off.  Values are bit-identical to vs_step. */
+int vs_step_jac(vs_handle h, const float* actions, int64_t env_stride, int64_t dim_stride);
 /* rollout() with DummyPolicy (P/sampling/rollout.py:185-239, P/policies/feed_forward/dummy.py:77-84):
  * k_steps env steps in ONE launch with on-device uniform actions in act_space, state kept in registers.
  * record != 0 streams obs/act/rew/done of every step into the VS_TRAJ_* buffers (k_steps <= vs_traj_capacity). */

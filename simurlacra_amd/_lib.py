@@ -9,7 +9,7 @@ VS_OK, VS_ERR_ARG, VS_ERR_HIP, VS_ERR_STATE, VS_ERR_NAN = 0, -1, -2, -3, -4
 ENV_TYPES = {"omo": 0, "bob": 1, "qq-su": 2, "qcp-su": 3, "qbb": 4, "qq-st": 5, "qcp-st": 6, "pend": 7, "bob-d": 8}
 (VS_STATE, VS_OBS, VS_REW, VS_DONE, VS_HIDDEN, VS_STEPCOUNT, VS_ERRFLAG, VS_RETURNS, VS_PARAMS, VS_CONSTS,
  VS_EP_RETURNS, VS_EP_LENGTHS, VS_EP_ENVIDX, VS_EP_COUNT, VS_TRAJ_OBS, VS_TRAJ_ACT, VS_TRAJ_REW, VS_TRAJ_DONE,
- VS_FAILED, VS_EPSTAT_COUNT, VS_EPSTAT_RETSUM, VS_EPSTAT_LENSUM) = range(22)
+ VS_FAILED, VS_EPSTAT_COUNT, VS_EPSTAT_RETSUM, VS_EPSTAT_LENSUM, VS_JAC_STATE, VS_JAC_REW, VS_JAC_OBS) = range(25)
 VS_FLAG_SIMPLE_DYNAMICS, VS_FLAG_LONG_POLE, VS_FLAG_ACT_NORM = 1, 2, 4
 VS_DP_NORMAL, VS_DP_UNIFORM = 0, 1
 
@@ -49,6 +49,7 @@ _SIGNATURES = {
     "vs_set_index_offset": (C.c_int, [_P, C.c_uint32]),
     "vs_set_auto_reset": (C.c_int, [_P, C.c_int, C.c_uint64]),
     "vs_step": (C.c_int, [_P, _P, C.c_int64, C.c_int64]),
+    "vs_step_jac": (C.c_int, [_P, _P, C.c_int64, C.c_int64]),
     "vs_step_random": (C.c_int, [_P, C.c_uint64, C.c_int, C.c_int]),
     "vs_seek_random": (C.c_int, [_P, C.c_uint64]),
     "vs_set_traj_capacity": (C.c_int, [_P, C.c_int]),

@@ -50,6 +50,7 @@ struct Dev {
     unsigned ep_cap;
     float *traj_obs, *traj_act, *traj_rew;
     uint8_t* traj_done;
+    float *jac_s, *jac_r, *jac_o;  // step Jacobians (vs_step_jac), allocated on first use
     int n, ld;
 };
 
@@ -328,6 +329,79 @@ template <class E, bool UNI, bool AR>
 __global__ __launch_bounds__(BLOCK) void k_step(Task T, Dev d, const float* __restrict__ act, long env_stride,
                                                 long dim_stride, uint64_t seed) {
     step_body<E, UNI, AR>(T, d, act, env_stride, dim_stride, seed, (int)blockIdx.x);
+}
+
+// ---------------------------------------------------------------------------------------------------- Jacobian kernel
+// vs_step_jac: vs_step plus d(s', r, obs') / d(s, a) by forward-mode differentiation of the very same step code
+// (Dual<S+A> instead of float, vecsim_dual.h).  What the fork obtains with torch autograd around its re-implemented
+// QCartPole dynamics (P/sampling/rollout.py:836-837, quanser_cartpole.py:233-431) -- here for every family.
+// Input x = (s_0 .. s_{S-1}, a_0 .. a_{A-1}); the hidden state (qcp th_ddot, qbb plate angles) is held constant.
+// Layouts: jac_s [S][S+A][ld], jac_r [S+A][ld], jac_o [O][S+A][ld].  The step values come from the float path and are
+// bit-identical to vs_step.
+template <class E, bool UNI>
+__global__ __launch_bounds__(BLOCK) void k_step_jac(Task T, Dev d, const float* __restrict__ act, long env_stride,
+                                                    long dim_stride) {
+    int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= d.ld) return;
+    constexpr int NI = E::S + E::A;
+    using D = Dual<NI>;
+    const size_t ld = d.ld;
+    float c[E::K];
+    load_consts<E, UNI>(d, i, c, 0, E::KS);
+    D s[E::S], h[E::H > 0 ? E::H : 1], a[E::A], ob[E::O];
+    bool valid = i < d.n;
+#pragma unroll
+    for (int j = 0; j < E::S; ++j) {
+        s[j] = D(d.state[j * ld + i]);
+        s[j].d[j] = 1.f;
+    }
+#pragma unroll
+    for (int j = 0; j < E::H; ++j) h[j] = D(d.hidden[j * ld + i]);
+#pragma unroll
+    for (int j = 0; j < E::A; ++j) {
+        a[j] = D(valid ? act[(size_t)i * env_stride + (size_t)j * dim_stride] : 0.f);
+        a[j].d[E::S + j] = 1.f;
+    }
+    int step = d.step[i];
+    bool yielded = E::FINAL != FINAL_NONE ? d.yielded[i] != 0 : false;
+    // values: the float path, so that they are bit-identical to vs_step (operator-by-operator dual arithmetic cannot
+    // reproduce the FMA contraction of the float expressions); tangents: the dual path on the same inputs
+    float sf[E::S], hf[E::H > 0 ? E::H : 1], af[E::A], obf[E::O];
+#pragma unroll
+    for (int j = 0; j < E::S; ++j) sf[j] = s[j].v;
+#pragma unroll
+    for (int j = 0; j < E::H; ++j) hf[j] = h[j].v;
+#pragma unroll
+    for (int j = 0; j < E::A; ++j) af[j] = a[j].v;
+    int step_d = step;
+    bool yielded_d = yielded;
+    StepOut of = step_one<E, float>(T, c, sf, hf, af, step, yielded, (const float*)nullptr);
+    E::observe(sf, obf);
+    StepOutT<D> o = step_one<E, D>(T, c, s, h, a, step_d, yielded_d, (const D*)nullptr);
+    E::observe(s, ob);
+    d.ret[i] = d.ret[i] + of.rew;
+    d.rew[i] = of.rew;
+    d.done[i] = of.done;
+    d.failed[i] = of.failed;
+    if (of.err && valid) d.err[i] = 1;
+#pragma unroll
+    for (int j = 0; j < E::S; ++j) {
+        d.state[j * ld + i] = sf[j];
+#pragma unroll
+        for (int k = 0; k < NI; ++k) d.jac_s[((size_t)j * NI + k) * ld + i] = s[j].d[k];
+    }
+#pragma unroll
+    for (int j = 0; j < E::H; ++j) d.hidden[j * ld + i] = hf[j];
+#pragma unroll
+    for (int j = 0; j < E::O; ++j) {
+        d.obs[j * ld + i] = obf[j];
+#pragma unroll
+        for (int k = 0; k < NI; ++k) d.jac_o[((size_t)j * NI + k) * ld + i] = ob[j].d[k];
+    }
+#pragma unroll
+    for (int k = 0; k < NI; ++k) d.jac_r[(size_t)k * ld + i] = o.rew.d[k];
+    d.step[i] = step;
+    if (E::FINAL != FINAL_NONE) d.yielded[i] = yielded;
 }
 
 // ---------------------------------------------------------------------------------------------------- rollout kernel
@@ -1159,6 +1233,27 @@ int vs_seek_random(vs_handle h, uint64_t step_index) {
     return VS_OK;
 }
 
+int vs_step_jac(vs_handle h, const float* actions, int64_t env_stride, int64_t dim_stride) {
+    if (!h || !actions) return fail(h, VS_ERR_ARG, "vs_step_jac: NULL argument");
+    if (!is_device_ptr(actions)) return fail(h, VS_ERR_ARG, "vs_step_jac: actions must be device memory");
+    if (h->auto_reset) return fail(h, VS_ERR_STATE, "vs_step_jac: switch auto-reset off (the Jacobian of a reset is meaningless)");
+    HIPCHK(h, hipSetDevice(h->device));
+    const EnvInfo& ei = ENV_INFO[h->type];
+    if (!h->d.jac_s) {
+        size_t ni = (size_t)(ei.S + ei.A), ld = h->d.ld;
+        int rc;
+        if ((rc = dalloc(h, &h->d.jac_s, ei.S * ni * ld))) return rc;
+        if ((rc = dalloc(h, &h->d.jac_r, ni * ld))) return rc;
+        if ((rc = dalloc(h, &h->d.jac_o, ei.O * ni * ld))) return rc;
+    }
+    bool uni = h->uniform && h->dr.n == 0 && h->d.pbuf_n == 0;
+    dim3 g = grid_for(h->d.ld), b(BLOCK);
+    if (uni) { DISPATCH_ENV(h->type, hipLaunchKernelGGL((k_step_jac<E, true>), g, b, 0, h->stream, h->task, h->d, actions, (long)env_stride, (long)dim_stride)); }
+    else { DISPATCH_ENV(h->type, hipLaunchKernelGGL((k_step_jac<E, false>), g, b, 0, h->stream, h->task, h->d, actions, (long)env_stride, (long)dim_stride)); }
+    HIPCHK(h, hipGetLastError());
+    return VS_OK;
+}
+
 int vs_set_traj_capacity(vs_handle h, int t_max) {
     if (!h || t_max < 0) return fail(h, VS_ERR_ARG, "vs_set_traj_capacity: bad argument");
     if (t_max <= h->traj_cap) return VS_OK;
@@ -1318,6 +1413,9 @@ static bool buf_info(vs_handle h, int which, void** p, size_t* bytes) {
         case VS_EPSTAT_COUNT: *p = d.es_count; *bytes = ld * 4; return true;
         case VS_EPSTAT_RETSUM: *p = d.es_retsum; *bytes = ld * 4; return true;
         case VS_EPSTAT_LENSUM: *p = d.es_lensum; *bytes = ld * 4; return true;
+        case VS_JAC_STATE: *p = d.jac_s; *bytes = d.jac_s ? (size_t)ei.S * (ei.S + ei.A) * ld * 4 : 0; return true;
+        case VS_JAC_REW: *p = d.jac_r; *bytes = d.jac_r ? (size_t)(ei.S + ei.A) * ld * 4 : 0; return true;
+        case VS_JAC_OBS: *p = d.jac_o; *bytes = d.jac_o ? (size_t)ei.O * (ei.S + ei.A) * ld * 4 : 0; return true;
         default: return false;
     }
 }

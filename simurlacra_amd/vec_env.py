@@ -302,6 +302,32 @@ class VecSimEnv:
         """Reposition the action stream of step_random (absolute step index, see include/vecsim.h)."""
         self._check(self._lib.vs_seek_random(self._h, int(step_index)), "vs_seek_random")
 
+    def _act_strides(self, actions):
+        A = self.dims["A"]
+        if not hasattr(actions, "data_ptr"):
+            raise TypeErr(given=actions, expected_type="torch.Tensor (device)")
+        if not actions.is_cuda or str(actions.dtype) != "torch.float32":
+            raise TypeErr(msg="actions must be a float32 tensor on the GPU")
+        shp = tuple(actions.shape)
+        if shp == (self.n_envs, A) or (A == 1 and shp == (self.n_envs,)):
+            return (actions.stride(0), actions.stride(1)) if actions.dim() == 2 else (actions.stride(0), 0)
+        if len(shp) == 2 and shp[0] == A and shp[1] in (self.n_envs, self.ld):
+            return actions.stride(1), actions.stride(0)
+        raise ShapeErr(given=actions, expected_match=(self.n_envs, A))
+
+    def step_jac(self, actions):
+        """vs_step plus the step Jacobians; returns dict(state=[N,S,S+A], rew=[N,S+A], obs=[N,O,S+A]) (host copies)."""
+        es, ds = self._act_strides(actions)
+        self._check(self._lib.vs_step_jac(self._h, C.c_void_p(actions.data_ptr()), es, ds), "vs_step_jac")
+        S, A, O = self.dims["S"], self.dims["A"], self.dims["O"]
+        out = {}
+        for key, which, rows in (("state", L.VS_JAC_STATE, S), ("rew", L.VS_JAC_REW, 1), ("obs", L.VS_JAC_OBS, O)):
+            buf = np.empty((rows * (S + A), self.ld), dtype=np.float32)
+            self._check(self._lib.vs_copy_to_host(self._h, which, buf.ctypes.data_as(C.c_void_p)), "vs_copy_to_host")
+            arr = buf[:, : self.n_envs].reshape(rows, S + A, self.n_envs).transpose(2, 0, 1)
+            out[key] = np.ascontiguousarray(arr[:, 0] if key == "rew" else arr)
+        return out
+
     def step_random(self, k_steps=1, seed=0, record=False):
         if record and k_steps > self._traj_cap:
             self._check(self._lib.vs_set_traj_capacity(self._h, int(k_steps)), "vs_set_traj_capacity")
@@ -454,6 +480,32 @@ class MixedVecSimEnv:
     def _check(self, rc, what):
         if rc != 0:
             raise RuntimeError(f"{what} failed ({rc}): {self._lib.vs_mixed_last_error(self._h).decode()}")
+
+    def _act_strides(self, actions):
+        A = self.dims["A"]
+        if not hasattr(actions, "data_ptr"):
+            raise TypeErr(given=actions, expected_type="torch.Tensor (device)")
+        if not actions.is_cuda or str(actions.dtype) != "torch.float32":
+            raise TypeErr(msg="actions must be a float32 tensor on the GPU")
+        shp = tuple(actions.shape)
+        if shp == (self.n_envs, A) or (A == 1 and shp == (self.n_envs,)):
+            return (actions.stride(0), actions.stride(1)) if actions.dim() == 2 else (actions.stride(0), 0)
+        if len(shp) == 2 and shp[0] == A and shp[1] in (self.n_envs, self.ld):
+            return actions.stride(1), actions.stride(0)
+        raise ShapeErr(given=actions, expected_match=(self.n_envs, A))
+
+    def step_jac(self, actions):
+        """vs_step plus the step Jacobians; returns dict(state=[N,S,S+A], rew=[N,S+A], obs=[N,O,S+A]) (host copies)."""
+        es, ds = self._act_strides(actions)
+        self._check(self._lib.vs_step_jac(self._h, C.c_void_p(actions.data_ptr()), es, ds), "vs_step_jac")
+        S, A, O = self.dims["S"], self.dims["A"], self.dims["O"]
+        out = {}
+        for key, which, rows in (("state", L.VS_JAC_STATE, S), ("rew", L.VS_JAC_REW, 1), ("obs", L.VS_JAC_OBS, O)):
+            buf = np.empty((rows * (S + A), self.ld), dtype=np.float32)
+            self._check(self._lib.vs_copy_to_host(self._h, which, buf.ctypes.data_as(C.c_void_p)), "vs_copy_to_host")
+            arr = buf[:, : self.n_envs].reshape(rows, S + A, self.n_envs).transpose(2, 0, 1)
+            out[key] = np.ascontiguousarray(arr[:, 0] if key == "rew" else arr)
+        return out
 
     def step_random(self, k_steps=1, seed=0, record=False):
         if record:

@@ -694,3 +694,70 @@ def test_full_size_mixed_config5_rank_shard(vs):
     solo.step_random(120, seed=5)
     assert np.array_equal(solo.get(L.VS_STATE), a_m[1].get(L.VS_STATE))
     assert a_m[2].get(L.VS_EPSTAT_COUNT).sum() > per // 2  # ball-on-beam episodes are short under a random policy
+
+
+@pytest.mark.parametrize("name", ENVS)
+def test_step_jacobians_against_finite_differences(vs, name):
+    """vs_step_jac (forward-mode differentiation of the step code in the kernel) against central finite differences of the
+    fp64 oracle, on the entries where two step sizes of the finite difference agree (i.e. away from the kinks of clip,
+    dead zone, fold and done); the step VALUES must equal vs_step bit for bit"""
+    L = vs._lib
+    n = 768
+    rng = np.random.default_rng(11)
+    ref = cpu_ref.make_ref(name, **KW[name])
+    P = ref.nominal_params(n).astype(np.float32).astype(np.float64)
+    slo, shi, alo, ahi = ref.bounds(P)
+    state = f32(0.5 * (slo + shi) + rng.uniform(-0.6, 0.6, slo.shape) * 0.5 * (shi - slo)).astype(np.float64)
+    hidden = f32(rng.uniform(-1, 1, (n, ref.H)) * (20 if name.startswith("qcp") else 0.1)).astype(np.float64)
+    act = f32(rng.uniform(0.35, 0.9, alo.shape) * ahi * rng.choice([-1, 1], alo.shape)).astype(np.float64)
+    act[: n // 8] *= 1.5  # some clipped actions: zero action gradient
+    act = f32(act).astype(np.float64)
+    curr = rng.integers(0, 50, n)
+    a = vs.VecSimEnv(name, n, **KW[name])
+    b = vs.VecSimEnv(name, n, **KW[name])
+    for e in (a, b):
+        setup_lanes(e, L, P, state, hidden, curr)
+    J = a.step_jac(dev(act))
+    b.step(dev(act))
+    for which in (L.VS_STATE, L.VS_OBS, L.VS_REW, L.VS_DONE, L.VS_HIDDEN, L.VS_STEPCOUNT):
+        assert np.array_equal(a.get(which), b.get(which))
+    S, A, O = ref.S, ref.A, ref.O
+    assert J["state"].shape == (n, S, S + A) and J["rew"].shape == (n, S + A) and J["obs"].shape == (n, O, S + A)
+    x0 = np.concatenate([state, act], axis=1)
+    scale = np.concatenate([np.maximum(np.abs(shi), 1e-3), np.maximum(np.abs(ahi), 1e-3)], axis=1)
+
+    def fd(eps_rel):
+        js = np.zeros((n, S, S + A)); jr = np.zeros((n, S + A)); jo = np.zeros((n, O, S + A))
+        for k in range(S + A):
+            h_ = eps_rel * scale[:, k]
+            outs = []
+            for sgn in (+1, -1):
+                x = x0.copy()
+                x[:, k] += sgn * h_
+                outs.append(ref.step(x[:, :S], hidden, x[:, S:], P, curr))
+            js[:, :, k] = (outs[0]["state"] - outs[1]["state"]) / (2 * h_[:, None])
+            jr[:, k] = (outs[0]["rew"] - outs[1]["rew"]) / (2 * h_)
+            jo[:, :, k] = (outs[0]["obs"] - outs[1]["obs"]) / (2 * h_[:, None])
+        return js, jr, jo
+
+    f1, f2 = fd(1e-6), fd(1e-5)
+    checked = 0
+    for got, g1, g2, tag in zip((J["state"], J["rew"], J["obs"]), f1, f2, ("state", "rew", "obs")):
+        mag = np.maximum(np.abs(g1), np.abs(g2))
+        smooth = np.abs(g1 - g2) <= 1e-4 * mag + 1e-7 * (1 + mag.max())
+        err = np.abs(got - g1)
+        tol = 3e-3 * np.abs(g1) + 3e-4 * (np.abs(g1[smooth]).max() if smooth.any() else 1.0)
+        bad = smooth & (err > tol)
+        assert bad.mean() < 2e-3, (tag, int(bad.sum()), float(err[bad].max()) if bad.any() else 0.0)
+        assert smooth.mean() > 0.9, (tag, float(smooth.mean()))
+        checked += int(smooth.sum())
+    # structure: clipped actions have zero action-gradient of the next state
+    clipped = (np.abs(act) > ahi).all(axis=1)
+    if name != "bob-d":
+        assert clipped.sum() > 10 and np.abs(J["state"][clipped][:, :, S:]).max() == 0.0
+    assert checked > 0.9 * n * (S + 1 + O) * (S + A)
+    with pytest.raises(RuntimeError):
+        a.set_auto_reset(True)
+        a.step_jac(dev(act))
+    a.close()
+    b.close()
