@@ -36,9 +36,13 @@ sys.path.insert(0, ROOT)
 #   fused rollout kernel with record: per step only the records leave the chip: 4*(O + A + 1) + 1; state/constants
 #   are read and written once per launch (amortised over `chunk` steps and added below)
 DIMS = {"omo": dict(S=2, A=1, O=2, P=3, H=0), "bob": dict(S=4, A=1, O=4, P=8, H=0), "qq-su": dict(S=4, A=1, O=6, P=11, H=0),
-        "qcp-su": dict(S=4, A=1, O=5, P=17, H=1), "qbb": dict(S=8, A=2, O=8, P=20, H=2)}
+        "qcp-su": dict(S=4, A=1, O=5, P=17, H=1), "qbb": dict(S=8, A=2, O=8, P=20, H=2),
+        "qq-st": dict(S=4, A=1, O=6, P=11, H=0), "qcp-st": dict(S=4, A=1, O=5, P=17, H=1),
+        "pend": dict(S=2, A=1, O=3, P=5, H=0), "bob-d": dict(S=4, A=1, O=4, P=8, H=0)}
 ENV_KW = {"omo": dict(dt=0.02, max_steps=300), "bob": dict(dt=0.01, max_steps=500), "qq-su": dict(dt=0.004, max_steps=4000),
-          "qcp-su": dict(dt=0.002, max_steps=8000), "qbb": dict(dt=0.01, max_steps=500)}
+          "qcp-su": dict(dt=0.002, max_steps=8000), "qbb": dict(dt=0.01, max_steps=500),
+          "qq-st": dict(dt=0.01, max_steps=500), "qcp-st": dict(dt=0.01, max_steps=300),
+          "pend": dict(dt=0.02, max_steps=400, init_state=np.array([0.1, 0.2])), "bob-d": dict(dt=0.01, max_steps=500)}
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
 
 
@@ -52,56 +56,68 @@ def bytes_fused_step(d, chunk, record):
     return per_step + per_launch / chunk
 
 
-def cpu_baseline(env_name, n_envs, budget_s=12.0):
-    """The oracle (NumPy port of the reference algorithm, fp64, vectorised over envs) on the host cores of this box."""
+def _cpu_worker(args):
+    """one core: the oracle (NumPy fp64, vectorised over its share of the envs) stepping with auto-reset for budget_s"""
+    env_name, n_envs, budget_s, seed = args
+    os.environ.setdefault("OMP_NUM_THREADS", "1")
     from oracle import cpu_ref
 
     kw = ENV_KW[env_name]
     ref = cpu_ref.make_ref(env_name, **kw)
-    rng = np.random.default_rng(0)
+    rng = np.random.default_rng(seed)
     params = ref.nominal_params(n_envs)
-    lo, hi = ref.init_bounds(params) if env_name != "bob" else ref.init_bounds(params, 0)
-    state = rng.uniform(lo, hi)
-    if env_name == "qbb":
-        state = ref.state_from_init(ref.polar_to_init(state))
+    lo, hi = ref.init_bounds(params) if not env_name.startswith("bob") else ref.init_bounds(params, 0)
+
+    def fresh_states():
+        st = rng.uniform(lo, hi)
+        return ref.state_from_init(ref.polar_to_init(st)) if env_name == "qbb" else st
+
+    state = fresh_states()
     hidden = np.zeros((n_envs, ref.H))
     _, _, alo, ahi = ref.bounds(params)
     steps = np.zeros(n_envs, dtype=np.int64)
     t0 = time.perf_counter()
-    done_steps = 0
-    while True:
-        act = rng.uniform(alo, ahi)
-        out = ref.step(state, hidden, act, params, steps)
+    n_steps = 0
+    while time.perf_counter() - t0 < budget_s:
+        out = ref.step(state, hidden, rng.uniform(alo, ahi), params, steps)
         state, hidden, steps = out["state"], out["hidden"], out["curr_step"]
         d = out["done"]
         if d.any():  # auto-reset, as on the device
-            fresh = rng.uniform(lo, hi)
-            if env_name == "qbb":
-                fresh = ref.state_from_init(ref.polar_to_init(fresh))
-            state[d] = fresh[d]
+            state[d] = fresh_states()[d]
             hidden[d] = 0
             steps[d] = 0
-        done_steps += 1
-        if time.perf_counter() - t0 > budget_s:
-            break
+        n_steps += 1
     el = time.perf_counter() - t0
-    vec = n_envs * done_steps / el
-    # scalar mode: one env object stepped in a Python loop (how the reference itself is driven, minus its deepcopy)
-    p1, s1, h1, st1 = params[:1], state[:1].copy(), hidden[:1].copy(), steps[:1].copy()
-    t0 = time.perf_counter()
-    k = 0
-    while time.perf_counter() - t0 < 3.0:
-        o = ref.step(s1, h1, rng.uniform(alo[:1], ahi[:1]), p1, st1)
-        s1, h1, st1 = o["state"], o["hidden"], o["curr_step"]
-        if o["done"][0]:
-            s1, st1 = rng.uniform(lo[:1], hi[:1]) if env_name != "qbb" else s1 * 0, st1 * 0
-        k += 1
-    scalar = k / (time.perf_counter() - t0)
-    return dict(value=vec, unit="env-steps/s", cores=1, kind="port",
-                sample=f"oracle/cpu_ref.py (NumPy fp64, vectorised over {n_envs} envs, 1 thread), {done_steps} batch steps "
-                       f"in {el:.1f} s incl. auto-reset; scalar N=1 loop: {scalar:.0f} env-steps/s; "
-                       f"reference Pyrado itself: 2.1-2.6e3 env-steps/s/core (BASELINE.md, measured in the build container)",
-                scalar_value=scalar, host_cores=os.cpu_count())
+    # scalar mode: one env stepped in a Python loop (how the reference itself is driven, minus its deepcopy)
+    k, t1 = 0, time.perf_counter()
+    if seed == 0:
+        p1, s1, h1, st1 = params[:1], state[:1].copy(), hidden[:1].copy(), steps[:1].copy()
+        while time.perf_counter() - t1 < 2.0:
+            o = ref.step(s1, h1, rng.uniform(alo[:1], ahi[:1]), p1, st1)
+            s1, h1, st1 = o["state"], o["hidden"], o["curr_step"]
+            if o["done"][0]:
+                s1, st1 = fresh_states()[:1], st1 * 0
+            k += 1
+    return n_envs * n_steps / el, n_steps, el, k / max(time.perf_counter() - t1, 1e-9)
+
+
+def cpu_baseline(env_name, n_envs, budget_s=10.0):
+    """CPU baseline beside the GPU number: the oracle (the NumPy port of the reference algorithm) on the host cores of
+    this box, one process per core, each vectorised over its share of the same 65 536-env workload.  Runs BEFORE the GPU
+    is touched (worker processes are forked from a process that has not initialised HIP)."""
+    import multiprocessing as mp
+
+    cores = max(1, min(16, os.cpu_count() or 1))  # the GPU box gives one job 16 CPU cores
+    share = n_envs // cores
+    with mp.get_context("fork").Pool(cores) as pool:
+        res = pool.map(_cpu_worker, [(env_name, share, budget_s, r) for r in range(cores)])
+    total = float(sum(r[0] for r in res))
+    return dict(value=total, unit="env-steps/s", cores=cores, kind="port",
+                sample=f"oracle/cpu_ref.py (NumPy fp64) in {cores} processes x {share} envs, vectorised, {res[0][1]} batch steps "
+                       f"per process in {res[0][2]:.1f} s incl. auto-reset; one process alone: {res[0][0]:.3g} env-steps/s; scalar N=1 "
+                       f"loop: {res[0][3]:.0f} env-steps/s; reference Pyrado itself: 2.1-2.6e3 env-steps/s/core (BASELINE.md, "
+                       f"measured in the build container)",
+                single_process_value=float(res[0][0]), scalar_value=float(res[0][3]), host_cores=os.cpu_count())
 
 
 def main():
@@ -120,13 +136,17 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     args = ap.parse_args()
 
-    import torch
-
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         args.gpus = world
+    cpu_base = None
+    if not args.no_cpu_baseline and world == 1:
+        cpu_base = cpu_baseline(args.env, min(args.envs, 65536))  # before any HIP call (forked workers)
+
+    import torch
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -154,7 +174,8 @@ def main():
     chunk = max(1, min(args.chunk, args.steps))
     n_launch = (args.steps + chunk - 1) // chunk
     steps = n_launch * chunk if args.mode == "fused" else args.steps
-    act_hi = {"omo": 30.0, "bob": 29.43, "qq-su": 4.5, "qcp-su": 6.0, "qbb": 3.0}[args.env]
+    act_hi = {"omo": 30.0, "bob": 29.43, "qq-su": 4.5, "qcp-su": 6.0, "qbb": 3.0, "qq-st": 4.5, "qcp-st": 6.0, "pend": 3.5,
+              "bob-d": 29.43}[args.env]
 
     graph = None
 
@@ -266,10 +287,7 @@ def main():
             "episodes": {"completed": ep["episodes"], "mean_return": ep["mean_return"], "mean_length": ep["mean_length"]},
             "nan_flags": errs,
         }
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args.env, min(n, 65536))
-        else:
-            out["cpu_baseline"] = None
+        out["cpu_baseline"] = cpu_base
         print(json.dumps(out), flush=True)
     env.close()
     if dist:
