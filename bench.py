@@ -149,12 +149,17 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # BENCH_REHEARSAL=1: every rank on GPU 0 with the gloo backend -- a 1-GPU rehearsal of the multi-rank code path
+    # (the real runs use one GPU per rank and RCCL)
+    rehearsal = os.environ.get("BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("gloo" if rehearsal else "nccl", rank=rank, world_size=world)
 
     import simurlacra_amd as vs
     from simurlacra_amd import _lib as L
@@ -228,7 +233,7 @@ def main():
     # reduced on the device, three doubles per rank on the wire
     cnt_t, rs_t, ls_t = (env.tensor(w)[0, :n] for w in (L.VS_EPSTAT_COUNT, L.VS_EPSTAT_RETSUM, L.VS_EPSTAT_LENSUM))
     ep = gather_episode_stats(cnt_t, rs_t, ls_t)
-    el_t = torch.tensor([el], device=f"cuda:{local_rank}", dtype=torch.float64)
+    el_t = torch.tensor([el], device="cpu" if rehearsal else f"cuda:{local_rank}", dtype=torch.float64)
     if dist:
         dist.all_reduce(el_t, op=dist.ReduceOp.MAX)
     el = float(el_t.item())

@@ -28,6 +28,8 @@ def gather_episode_stats(count, retsum, lensum, group=None):
 
     mine = torch.stack([retsum.double().sum(), count.double().sum(), lensum.double().sum()])
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        if dist.get_backend(group) == "gloo":
+            mine = mine.cpu()  # CPU rehearsal of the multi-rank path; RCCL takes the device tensor as it is
         parts = [torch.zeros_like(mine) for _ in range(dist.get_world_size(group))]
         dist.all_gather(parts, mine, group=group)
         per_rank = torch.stack(parts)
