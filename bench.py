@@ -6,10 +6,12 @@ bench.py -- env-steps/sec of the MI355X-native stepper on BASELINE.json's metric
   python bench.py [--gpus N] [--steps K] [--warmup W]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-A "step" is one pass of the hot path over the batch: every one of the 65 536 environments of a rank advances by one
-SimPyEnv.step (reward -> clip -> dead zone -> integrate -> done -> observe), finished lanes are auto-reset in the same
-kernel, the action comes from the on-device uniform random policy (DummyPolicy).  State, constants and actions are
-resident in HBM when the timed region starts.  Each rank owns 65 536 envs on its own GPU (weak scaling, the batch
+A "step" is one pass of the hot path over the batch = one launch.  In the default fused mode a launch advances every one of
+the 65 536 environments of a rank by `--chunk` (100) env steps -- SimPyEnv.step: reward -> clip -> dead zone -> integrate
+-> done -> observe, finished lanes auto-reset in the same kernel, actions from the on-device uniform random policy
+(DummyPolicy), obs/act/rew/done of every env step recorded; in `--mode step` a launch is one env step.  `value` counts ENV
+steps: envs x env-steps-per-launch x K / time ("env_steps_per_step" in the JSON).  State and constants are resident in HBM
+when the timed region starts.  Each rank owns 65 536 envs on its own GPU (weak scaling, the batch
 shards embarrassingly); the only collective is an RCCL all-gather of completed-episode return statistics at the end.
 
 Modes (--mode):
@@ -123,8 +125,8 @@ def cpu_baseline(env_name, n_envs, budget_s=10.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=None, help="timed launches (default 200 fused / 2000 step mode)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed launches (default 20 fused / 200 step mode)")
     ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
     ap.add_argument("--env", default="qq-su", choices=sorted(DIMS))
     ap.add_argument("--mode", default="fused", choices=["fused", "step"])
@@ -176,9 +178,13 @@ def main():
     env.set_index_offset(first)  # global env index: lane streams do not depend on the number of GPUs
     env.set_auto_reset(True, seed=args.seed * 1000 + 1)
     env.reset(seed=args.seed * 7919 + 2)
-    chunk = max(1, min(args.chunk, args.steps))
-    n_launch = (args.steps + chunk - 1) // chunk
-    steps = n_launch * chunk if args.mode == "fused" else args.steps
+    if args.steps is None:
+        args.steps = 200 if args.mode == "fused" else 2000
+    if args.warmup is None:
+        args.warmup = 20 if args.mode == "fused" else 200
+    chunk = max(1, args.chunk)
+    steps = args.steps  # launches
+    per_step = chunk if (args.mode == "fused" or args.graph) else 1  # env steps per launch
     act_hi = {"omo": 30.0, "bob": 29.43, "qq-su": 4.5, "qcp-su": 6.0, "qbb": 3.0, "qq-st": 4.5, "qcp-st": 6.0, "pend": 3.5,
               "bob-d": 29.43}[args.env]
 
@@ -188,15 +194,15 @@ def main():
         act = (torch.rand(n, d["A"], device=f"cuda:{local_rank}") * 2 - 1) * act_hi  # DummyPolicy on the GPU
         env.step(act)
 
-    def run(k_steps):
+    def run(k_launches):
         if args.mode == "fused":
-            for _ in range((k_steps + chunk - 1) // chunk):
+            for _ in range(k_launches):
                 env.step_random(chunk, seed=args.seed + 3, record=bool(args.record))
         elif graph is not None:
-            for _ in range((k_steps + chunk - 1) // chunk):
+            for _ in range(k_launches):
                 graph.replay()
         else:
-            for _ in range(k_steps):
+            for _ in range(k_launches):
                 policy_and_step()
 
     if args.mode == "step":
@@ -214,7 +220,6 @@ def main():
             with torch.cuda.graph(graph, stream=side):
                 for _ in range(chunk):
                     policy_and_step()
-            steps = n_launch * chunk
     run(max(args.warmup, 1))
     env.sync()
     torch.cuda.synchronize()
@@ -240,7 +245,7 @@ def main():
     errs = env.error_count()
 
     if rank == 0:
-        total_env_steps = float(n) * steps * world
+        total_env_steps = float(n) * steps * per_step * world
         value = total_env_steps / el
         # roofline of the dominant kernel: HIP events on the kernel's own stream
         if args.mode == "fused":
@@ -274,7 +279,7 @@ def main():
         out = {
             "metric": "env-steps/sec whole node, 65 536 QQubeSwingUpSim envs, random policy",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": steps, "warmup": args.warmup,
-            "ms_per_step": el / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": el / steps * 1e3, "env_steps_per_step": per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.env} x {n} envs per GPU, dt {kw['dt']}, max_steps {kw['max_steps']}, uniform random "
                                    f"policy on device, auto-reset, mode={args.mode}"
