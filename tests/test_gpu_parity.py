@@ -761,3 +761,26 @@ def test_step_jacobians_against_finite_differences(vs, name):
         a.step_jac(dev(act))
     a.close()
     b.close()
+
+
+def test_maximum_size_batch_4m_lanes(vs):
+    """a batch far beyond the caches (4 194 304 QQube envs, ~0.8 GB of per-env buffers, 0.5 GB per step of traffic):
+    the first lanes behave exactly like the same lanes in a small handle; every lane advances; no error flags"""
+    L = vs._lib
+    n, m = 1 << 22, 4096
+    big = vs.VecSimEnv("qq-su", n, **KW["qq-su"])
+    small = vs.VecSimEnv("qq-su", m, **KW["qq-su"])
+    for e in (big, small):
+        e.set_params(np.tile(vs.nominal_params("qq-su"), (e.n_envs, 1)))
+        e.set_auto_reset(True, seed=3)
+        e.reset(seed=4)
+        e.step_random(24, seed=5)
+    act = torch.rand(n, 1, device="cuda") * 9 - 4.5
+    big.step(act)
+    small.step(act[:m].contiguous())
+    assert np.array_equal(big.get(L.VS_STATE)[:m], small.get(L.VS_STATE))
+    assert (big.get(L.VS_STEPCOUNT) == 25).all() and big.error_count() == 0
+    tail = big.get(L.VS_STATE)[-m:]
+    assert np.isfinite(tail).all() and np.abs(tail).max() > 0
+    big.close()
+    small.close()
