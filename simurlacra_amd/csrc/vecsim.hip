@@ -488,6 +488,9 @@ __device__ __forceinline__ void rollout_body(const Task& T, const Dev& d, int k_
             }
             if (d.log_episodes) append_episode(d, fin, i, ret, step);
             frozen |= done;
+            // early termination: a wave whose 64 rollouts have all ended has nothing left to do (the ballot is
+            // wave-uniform, so the whole wave leaves the loop together); with records on it keeps writing its frozen rows
+            if (!REC && __ballot(!frozen) == 0ull) break;
         }
 #ifdef VS_ABLATE_OBSERVE
         if (REC) { for (int j = 0; j < E::O; ++j) ob[j] = s[j % E::S]; }
