@@ -194,6 +194,9 @@ int vs_step_random(vs_handle h, uint64_t seed, int k_steps, int record);
  * steps it has taken.  vs_seek_random repositions that counter (0 = start of a fresh batch of rollouts). */
 int vs_seek_random(vs_handle h, uint64_t step_index);
 int vs_set_traj_capacity(vs_handle h, int t_max);
+/* first row of the VS_TRAJ_* buffers written by the next recording vs_step_random (default 0): consecutive launches can
+ * fill one long trajectory buffer, t0 + k_steps <= capacity */
+int vs_set_traj_offset(vs_handle h, int t0);
 /* Episode bookkeeping.  Always on: per-env accumulators VS_EPSTAT_* (plain per-lane adds, no atomics) -- what the
  * RCCL return gather reads.  Opt-in (vs_set_episode_log): every finished episode is also appended as (return, length,
  * env index) to the VS_EP_* ring, compacted with a wavefront ballot and one atomic per wave; that atomic is a shared

@@ -53,6 +53,7 @@ _SIGNATURES = {
     "vs_step_random": (C.c_int, [_P, C.c_uint64, C.c_int, C.c_int]),
     "vs_seek_random": (C.c_int, [_P, C.c_uint64]),
     "vs_set_traj_capacity": (C.c_int, [_P, C.c_int]),
+    "vs_set_traj_offset": (C.c_int, [_P, C.c_int]),
     "vs_set_episode_log": (C.c_int, [_P, C.c_int]),
     "vs_clear_episodes": (C.c_int, [_P]),
     "vs_mixed_create": (C.c_int, [C.POINTER(_P), C.c_int, C.POINTER(_P)]),

@@ -50,6 +50,7 @@ struct Dev {
     unsigned ep_cap;
     float *traj_obs, *traj_act, *traj_rew;
     uint8_t* traj_done;
+    int traj_t0;  // record row offset of the next vs_step_random(record = 1)
     float *jac_s, *jac_r, *jac_o;  // step Jacobians (vs_step_jac), allocated on first use
     int n, ld;
 };
@@ -413,6 +414,7 @@ __global__ __launch_bounds__(BLOCK) void k_step_jac(Task T, Dev d, const float* 
 template <class E, bool UNI, bool AR, bool REC>
 __device__ __forceinline__ void rollout_body(const Task& T, const Dev& d, int k_steps, uint64_t seed, uint64_t reset_seed,
                                              uint64_t epoch0, int block) {
+    const size_t rec0 = (size_t)d.traj_t0;  // first record row of this launch (vs_set_traj_offset)
     int i = block * BLOCK + threadIdx.x;
     if (i >= d.ld) return;
     const size_t ld = d.ld;
@@ -456,7 +458,7 @@ __device__ __forceinline__ void rollout_body(const Task& T, const Dev& d, int k_
             a[j] = E::sample_action(c, nrm ? -1.0f : alo[j], nrm ? 1.0f : ahi[j], Rng::to_u01(bits), j);  // act_space.sample_uniform()
         }
         if (REC) {
-            size_t tb = (size_t)t;
+            size_t tb = rec0 + (size_t)t;
 #pragma unroll
             for (int j = 0; j < E::O; ++j) d.traj_obs[(tb * E::O + j) * ld + i] = ob[j];
 #pragma unroll
@@ -473,8 +475,8 @@ __device__ __forceinline__ void rollout_body(const Task& T, const Dev& d, int k_
             rew = 0.f;
         }
         if (REC) {
-            d.traj_rew[(size_t)t * ld + i] = rew;
-            d.traj_done[(size_t)t * ld + i] = done;
+            d.traj_rew[(rec0 + (size_t)t) * ld + i] = rew;
+            d.traj_done[(rec0 + (size_t)t) * ld + i] = done;
         }
         bool fin = done && valid && !frozen;
         if (AR) {
@@ -1275,9 +1277,15 @@ int vs_set_traj_capacity(vs_handle h, int t_max) {
     return VS_OK;
 }
 
+int vs_set_traj_offset(vs_handle h, int t0) {
+    if (!h || t0 < 0) return fail(h, VS_ERR_ARG, "vs_set_traj_offset: bad argument");
+    h->d.traj_t0 = t0;
+    return VS_OK;
+}
+
 int vs_step_random(vs_handle h, uint64_t seed, int k_steps, int record) {
     if (!h || k_steps < 1) return fail(h, VS_ERR_ARG, "vs_step_random: bad argument");
-    if (record && k_steps > h->traj_cap) return fail(h, VS_ERR_STATE, "vs_step_random: k_steps exceeds vs_set_traj_capacity");
+    if (record && h->d.traj_t0 + k_steps > h->traj_cap) return fail(h, VS_ERR_STATE, "vs_step_random: traj offset + k_steps exceeds vs_set_traj_capacity");
     HIPCHK(h, hipSetDevice(h->device));
     uint64_t ep = h->epoch;
     h->epoch += (uint64_t)k_steps;
@@ -1327,7 +1335,7 @@ const char* vs_mixed_last_error(vs_mixed_handle m) { return m ? m->err.c_str() :
 int vs_mixed_step_random(vs_mixed_handle m, uint64_t seed, int k_steps, int record) {
     if (!m || k_steps < 1) return VS_ERR_ARG;
     for (int q = 0; q < m->n; ++q) {
-        if (record && k_steps > m->sub[q]->traj_cap) { m->err = "vs_mixed_step_random: k_steps exceeds a segment's vs_set_traj_capacity"; return VS_ERR_STATE; }
+        if (record && m->sub[q]->d.traj_t0 + k_steps > m->sub[q]->traj_cap) { m->err = "vs_mixed_step_random: k_steps exceeds a segment's vs_set_traj_capacity"; return VS_ERR_STATE; }
         if (m->sub[q]->auto_reset != m->sub[0]->auto_reset) { m->err = "vs_mixed_step_random: segments differ in auto-reset"; return VS_ERR_STATE; }
     }
     if (hipSetDevice(m->sub[0]->device) != hipSuccess) return VS_ERR_HIP;

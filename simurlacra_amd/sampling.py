@@ -52,6 +52,21 @@ class StepSequence:
         for k, v in extra.items():
             setattr(self, k, v)
 
+    @classmethod
+    def _packed(cls, observations, actions, rewards, rollout_info, done_last, dt, init_state):
+        """views into the sampler's packed arrays: no copies, no validation"""
+        ro = cls.__new__(cls)
+        ro.observations, ro.actions = observations, actions
+        ro.rewards = rewards.astype(np.float64)
+        ro.states, ro.env_infos, ro.complete = None, None, True
+        ro.rollout_info = rollout_info
+        ro.time = np.arange(len(rewards) + 1) * dt
+        ro.done = np.zeros(len(rewards), dtype=bool)
+        if len(rewards) and done_last:
+            ro.done[-1] = True
+        ro.init_state = init_state
+        return ro
+
     @property
     def length(self) -> int:
         return len(self.rewards)
@@ -237,64 +252,79 @@ class ParallelRolloutSampler:
             v.reset(init_state=arr, mask=mask, seed=lane_key)
         dev = f"cuda:{v.device}"
         obs_t = v.tensor(L.VS_OBS)[:, :n]
-        rew_t, done_t, st_t = v.tensor(L.VS_REW)[0, :n], v.tensor(L.VS_DONE)[0, :n], v.tensor(L.VS_STATE)[:, :n]
+        done_t, st_t = v.tensor(L.VS_DONE)[0, :n], v.tensor(L.VS_STATE)[:, :n]
+        rew_t = v.tensor(L.VS_REW)[0, :n]
         use_fused = isinstance(self.policy, DummyPolicy)
-        obs_rec, act_rec, rew_rec, done_rec = [], [], [], []
         state0 = st_t.t().clone()
-        alive = torch.ones(n, dtype=torch.bool, device=dev)
+        T_cap = int(max_steps)
         t = 0
         if use_fused:
-            # rollout() with DummyPolicy == vs_step_random: fused steps, on-device uniform actions, lanes freeze at done
-            while t < max_steps and bool(alive.any()):
-                k = int(min(self._chunk, max_steps - t))
+            # rollout() with DummyPolicy == vs_step_random: fused steps, on-device uniform actions, lanes freeze at done.
+            # Consecutive launches fill ONE device-side trajectory buffer; nothing is copied to the host inside the loop.
+            v.set_traj_capacity(T_cap)
+            while t < T_cap:
+                k = int(min(self._chunk, T_cap - t))
+                v.set_traj_offset(t)
                 v.step_random(k, seed=lane_key ^ 0xA0761D6478BD642F, record=True)
-                rec = v.traj(k)
-                obs_rec.append(rec["obs"]); act_rec.append(rec["act"]); rew_rec.append(rec["rew"]); done_rec.append(rec["done"])
-                alive = ~done_t.bool()
                 t += k
-            obs_all = np.concatenate(obs_rec); act_all = np.concatenate(act_rec)
-            rew_all = np.concatenate(rew_rec); done_all = np.concatenate(done_rec).astype(bool)
-            final_obs = obs_t.t().cpu().numpy()
+                if bool(done_t.bool().all()):  # one scalar sync per launch
+                    break
+            v.set_traj_offset(0)
+            tt = v.traj_tensors()
+            obs_T, act_T = tt["obs"][:t, :, :n], tt["act"][:t, :, :n]  # [T, dim, n]
+            rew_T, done_T = tt["rew"][:t, :n], tt["done"][:t, :n].bool()  # [T, n]
         else:
             policy = self.policy.to(dev) if hasattr(self.policy, "to") else self.policy
             if hasattr(policy, "eval"):
                 policy.eval() if eval else policy.train()
             v.use_stream(torch.cuda.current_stream().cuda_stream)
+            obs_rec, act_rec, rew_rec, done_rec = [], [], [], []
+            alive = torch.ones(n, dtype=torch.bool, device=dev)
             with torch.no_grad():
-                while t < max_steps:
+                while t < T_cap:
                     obs = obs_t.t()
                     act = policy(obs).to(torch.float32).reshape(n, A).contiguous()
-                    obs_rec.append(obs.clone()); act_rec.append(act)
+                    obs_rec.append(obs_t.clone())
+                    act_rec.append(act.t())
                     v.step(act)
-                    rew_rec.append(rew_t.clone()); done_rec.append(done_t.clone())
+                    rew_rec.append(rew_t.clone())
+                    done_rec.append(done_t.clone())
                     t += 1
-                    if t % 32 == 0 or t == max_steps:
+                    if t % 32 == 0 or t == T_cap:
                         alive &= ~torch.stack(done_rec[-32:]).bool().any(dim=0)
                         if not bool(alive.any()):
                             break
             v.use_stream(None)
-            obs_all = torch.stack(obs_rec).cpu().numpy(); act_all = torch.stack(act_rec).cpu().numpy()
-            rew_all = torch.stack(rew_rec).cpu().numpy(); done_all = torch.stack(done_rec).cpu().numpy().astype(bool)
-            final_obs = None
+            obs_T, act_T = torch.stack(obs_rec), torch.stack(act_rec)  # [T, dim, n]
+            rew_T, done_T = torch.stack(rew_rec), torch.stack(done_rec).bool()
         v.raise_on_error()
+        # ---- split into rollouts on the device: rollout j = steps 0 .. first done of lane j, packed lane-major ----
+        T = t
+        ar = torch.arange(n, device=dev)
+        any_done = done_T.any(dim=0)
+        first = torch.where(any_done, done_T.to(torch.uint8).argmax(dim=0), torch.full_like(ar, T - 1))
+        length = first + 1  # [n]
+        tgrid = torch.arange(T + 1, device=dev)[None, :]
+        mask = tgrid[:, :T] < length[:, None]  # [n, T]
+        mask_o = tgrid <= length[:, None]  # [n, T + 1]: one observation more than steps
+        obs_ext = torch.cat([obs_T, obs_t[None]], dim=0)  # the row after the last step is the current observation
+        obs_p = obs_ext.permute(2, 0, 1)[mask_o].cpu().numpy()
+        act_p = act_T.permute(2, 0, 1)[mask].cpu().numpy()
+        rew_p = rew_T.t()[mask].cpu().numpy()
+        done_last = done_T[first, ar].cpu().numpy()
+        length_h = length.cpu().numpy()
+        state0_h = state0.cpu().numpy()
         params = v.get(L.VS_PARAMS)
-        T = done_all.shape[0]
-        first_done = np.where(done_all.any(axis=0), done_all.argmax(axis=0), T - 1)
+        off = np.concatenate([[0], np.cumsum(length_h)])
+        off_o = np.concatenate([[0], np.cumsum(length_h + 1)])
+        dt = base.dt
         ros = []
         for j in range(n):
-            Lj = int(first_done[j]) + 1
-            if Lj < T:
-                last = obs_all[Lj, j]  # the obs recorded before step Lj is observe(s_Lj) (frozen / still stepping)
-            elif final_obs is not None:
-                last = final_obs[j]
-            else:
-                last = obs_t[:, j].cpu().numpy()
-            observations = np.concatenate([obs_all[:Lj, j], last[None]], axis=0)
-            info = dict(env_name=base.name, domain_param={k: float(x) for k, x in zip(v.param_names, params[j])},
+            Lj = int(length_h[j])
+            info = dict(env_name=base.name, domain_param=dict(zip(v.param_names, params[j].tolist())),
                         rollout_number=first_index + j)
-            ros.append(StepSequence(observations=observations, actions=act_all[:Lj, j], rewards=rew_all[:Lj, j],
-                                    time=np.arange(Lj + 1) * base.dt, rollout_info=info,
-                                    done_last=bool(done_all[Lj - 1, j]), init_state=state0[j].cpu().numpy()))
+            ros.append(StepSequence._packed(obs_p[off_o[j]:off_o[j + 1]], act_p[off[j]:off[j + 1]], rew_p[off[j]:off[j + 1]],
+                                            info, bool(done_last[j]), dt, state0_h[j]))
         return ros
 
     def sample(self, init_states: Optional[List[np.ndarray]] = None, domain_params: Optional[List[dict]] = None,

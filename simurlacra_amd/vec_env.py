@@ -328,10 +328,31 @@ class VecSimEnv:
             out[key] = np.ascontiguousarray(arr[:, 0] if key == "rew" else arr)
         return out
 
+    def set_traj_capacity(self, t_max):
+        if t_max > self._traj_cap:
+            self._check(self._lib.vs_set_traj_capacity(self._h, int(t_max)), "vs_set_traj_capacity")
+            self._traj_cap = int(t_max)
+
+    def set_traj_offset(self, t0=0):
+        """first record row of the next recording step_random (consecutive launches fill one long buffer)"""
+        self._check(self._lib.vs_set_traj_offset(self._h, int(t0)), "vs_set_traj_offset")
+        self._traj_t0 = int(t0)
+
+    def traj_tensors(self):
+        """zero-copy torch views of the record buffers: obs [T, O, ld], act [T, A, ld], rew [T, ld], done [T, ld]"""
+        import torch
+
+        out = {}
+        for key, which, rows, dt in (("obs", L.VS_TRAJ_OBS, self.dims["O"], "<f4"), ("act", L.VS_TRAJ_ACT, self.dims["A"], "<f4"),
+                                     ("rew", L.VS_TRAJ_REW, 1, "<f4"), ("done", L.VS_TRAJ_DONE, 1, "|u1")):
+            ptr = self._lib.vs_get(self._h, which)
+            shape = (self._traj_cap, rows, self.ld) if key in ("obs", "act") else (self._traj_cap, self.ld)
+            out[key] = torch.as_tensor(_DevArray(ptr, shape, dt, self), device=f"cuda:{self.device}")
+        return out
+
     def step_random(self, k_steps=1, seed=0, record=False):
-        if record and k_steps > self._traj_cap:
-            self._check(self._lib.vs_set_traj_capacity(self._h, int(k_steps)), "vs_set_traj_capacity")
-            self._traj_cap = int(k_steps)
+        if record and getattr(self, "_traj_t0", 0) + k_steps > self._traj_cap:
+            self.set_traj_capacity(getattr(self, "_traj_t0", 0) + int(k_steps))
         self._check(self._lib.vs_step_random(self._h, int(seed) & (2 ** 64 - 1), int(k_steps), int(bool(record))),
                     "vs_step_random")
 
