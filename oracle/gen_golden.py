@@ -374,6 +374,58 @@ def gen_wrappers():
     return out
 
 
+VARIANTS = {
+    # ctor / task options of the reference classes that change the hot path (flags of vs_task_cfg on the device)
+    "qcp_su_simple": ("qcp-su", dict(dt=0.002, max_steps=8000, simple_dynamics=True)),
+    "qcp_su_long": ("qcp-su", dict(dt=0.002, max_steps=8000, long=True)),
+    "qcp_su_tame_init": ("qcp-su", dict(dt=0.002, max_steps=8000, wild_init="False")),
+    "qbb_simple": ("qbb", dict(dt=0.01, max_steps=500, simple_dynamics=True)),
+    "qq_su_task_args": ("qq-su", dict(dt=0.004, max_steps=4000, task_args=dict(
+        state_des=np.array([0.3, -np.pi, 0.5, -0.2]), Q=np.diag([2.0, 0.5, 1e-2, 1e-3]), R=np.diag([1e-2])))),
+    "bob_task_args": ("bob", dict(dt=0.01, max_steps=500, task_args=dict(
+        state_des=np.array([0.2, 0.0, 0.0, 0.0]), Q=np.diag([1e4, 1e2, 1e2, 1e1]), R=np.diag([0.5])))),
+    "omo_inf_steps": ("omo", dict(dt=0.02)),  # max_steps = pyrado.inf: remaining_steps = 0, no time-out
+    "qcp_st_short_pole": ("qcp-st", dict(dt=0.01, max_steps=300, long=False, simple_dynamics=False)),
+}
+
+
+def gen_variants(m=40, seed=900):
+    out = {}
+    for vi, (tag, (name, kw)) in enumerate(VARIANTS.items()):
+        cls = ENVS[name][0]
+        env = cls(**kw)
+        rng = np.random.default_rng(seed + vi)
+        rec = {k: [] for k in ("state", "hidden", "act", "curr_step", "nstate", "nhidden", "obs", "rew", "done")}
+        dp = env.domain_param
+        for i in range(m):
+            env.reset(init_state=np.zeros(env.state_space.shape))
+            lo, hi = env.state_space.bound_lo, env.state_space.bound_up
+            u = rng.uniform(-1, 1, size=lo.shape)
+            if i % 5 == 0:
+                j = rng.integers(lo.size)
+                u[j] = np.sign(u[j]) * rng.uniform(0.999, 1.02)
+            state = 0.5 * (lo + hi) + 0.5 * (hi - lo) * u
+            hidden = rng.uniform(-60, 60, size=1) if HIDDEN[name] == 1 else (rng.uniform(-0.2, 0.2, size=2) if HIDDEN[name] == 2 else np.zeros(0))
+            act = rng.uniform(-1.3, 1.3, size=env.act_space.shape) * env.act_space.bound_up
+            curr = int(rng.integers(0, 200))
+            env.state = state.copy()
+            env._curr_step = curr
+            set_hidden(name, env, hidden)
+            obs, rew, done, _ = env.step(act.copy())
+            for k, v in zip(rec, (state, hidden, act, curr, np.array(env.state, dtype=np.float64), get_hidden(name, env),
+                                  np.array(obs, dtype=np.float64), float(rew), bool(done))):
+                rec[k].append(v)
+        for k, v in rec.items():
+            out[f"{tag}__{k}"] = np.array(v)
+        out[f"{tag}__params"] = params_to_vec(env, dp)
+        if hasattr(env.init_space, "bound_lo") and name != "qbb":  # Box init spaces only (bob: compound, qbb: polar)
+            init = np.array([env.init_space.sample_uniform() for _ in range(64)])
+            out[f"{tag}__init_lo"] = env.init_space.bound_lo
+            out[f"{tag}__init_hi"] = env.init_space.bound_up
+            assert ((init >= env.init_space.bound_lo) & (init <= env.init_space.bound_up)).all()
+    return out
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     m_step = {"omo": 256, "bob": 256, "qq-su": 256, "qcp-su": 256, "qbb": 128, "qq-st": 192, "qcp-st": 192, "pend": 192,
@@ -392,6 +444,8 @@ def main():
     if force or not os.path.exists(os.path.join(OUT, "cfg1_omo_500.npz")):
         np.savez_compressed(os.path.join(OUT, "cfg1_omo_500.npz"), **gen_cfg1())
         np.savez_compressed(os.path.join(OUT, "qbb_ik.npz"), **gen_ik())
+    if force or not os.path.exists(os.path.join(OUT, "variants.npz")):
+        np.savez_compressed(os.path.join(OUT, "variants.npz"), **gen_variants())
     if force or not os.path.exists(os.path.join(OUT, "wrappers.npz")):
         np.savez_compressed(os.path.join(OUT, "wrappers.npz"), **gen_wrappers())
     with open(os.path.join(OUT, "randomizers.json"), "w") as fh:

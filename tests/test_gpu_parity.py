@@ -65,7 +65,7 @@ def bound_margin(ref, nstate, params):
     return np.minimum(np.abs(nstate - slo), np.abs(nstate - shi)) / scale
 
 
-def check_step(env, L, ref, params, state, hidden, act, curr_step, exp, yielded=None):
+def check_step(env, L, ref, params, state, hidden, act, curr_step, exp, yielded=None, ref32=None):
     """exp: dict with state/obs/rew/done(/hidden) from the reference or the oracle (fp64)"""
     assert_state_close(ref, env.get(L.VS_STATE), exp["state"], params)
     # observe(): tight against the oracle's observe of the kernel's OWN next state (tests the trig), and against the
@@ -84,7 +84,8 @@ def check_step(env, L, ref, params, state, hidden, act, curr_step, exp, yielded=
     # bit-exact w.r.t. the kernel's own fp32 state: done == any(s' < lo32 | s' > hi32) | timeout
     slo, shi, _, _ = ref.bounds(f32(env.get(L.VS_PARAMS)).astype(np.float64))
     s32 = env.get(L.VS_STATE)
-    lo32, hi32 = cpu_ref.make_ref(ref.name, ref.dt, ref.max_steps, dtype=np.float32).bounds(env.get(L.VS_PARAMS))[:2]
+    ref32 = ref32 or cpu_ref.make_ref(ref.name, ref.dt, ref.max_steps, dtype=np.float32)
+    lo32, hi32 = ref32.bounds(env.get(L.VS_PARAMS))[:2]
     failed = ((s32 < lo32) | (s32 > hi32)).any(axis=1)
     timeout = (np.asarray(curr_step) + 1) >= ref.max_steps
     assert np.array_equal(env.get(L.VS_FAILED).astype(bool), failed)
@@ -784,3 +785,31 @@ def test_maximum_size_batch_4m_lanes(vs):
     assert np.isfinite(tail).all() and np.abs(tail).max() > 0
     big.close()
     small.close()
+
+
+def test_ctor_and_task_variants(vs, golden_dir):
+    """constructor / task options of the reference classes pushed through vs_task_cfg: simple_dynamics, long, wild_init,
+    task_args (state_des, Q, R), max_steps=inf, the short-pole stabilisation task (tests/golden/variants.npz)"""
+    from test_oracle_golden import VARIANTS
+
+    L = vs._lib
+    g = np.load(os.path.join(golden_dir, "variants.npz"))
+    for tag, (name, kw) in VARIANTS.items():
+        n = g[f"{tag}__state"].shape[0]
+        env = vs.VecSimEnv(name, n, **kw)
+        ref = cpu_ref.make_ref(name, **kw)
+        ref32 = cpu_ref.make_ref(name, dtype=np.float32, **kw)
+        P = np.tile(g[f"{tag}__params"], (n, 1))
+        np.testing.assert_allclose(env.get(L.VS_PARAMS)[0], g[f"{tag}__params"], rtol=1e-6, err_msg=tag)  # nominal set
+        setup_lanes(env, L, P, g[f"{tag}__state"], g[f"{tag}__hidden"], g[f"{tag}__curr_step"])
+        env.step(dev(g[f"{tag}__act"]))
+        exp = {k: g[f"{tag}__{v}"] for k, v in dict(state="nstate", obs="obs", rew="rew", done="done", hidden="nhidden").items()}
+        check_step(env, L, ref, P, None, None, None, g[f"{tag}__curr_step"], exp, ref32=ref32)
+        if f"{tag}__init_lo" in g.files:  # the init space the ctor flags select (wild_init, long)
+            env.reset(seed=5)
+            s0 = env.get(L.VS_STATE).astype(np.float64)
+            lo, hi = g[f"{tag}__init_lo"], g[f"{tag}__init_hi"]
+            eps = 1e-6 * np.maximum(1.0, np.abs(hi))
+            assert ((s0 >= lo - eps) & (s0 <= hi + eps)).all(), tag
+        assert env.error_count() == 0
+        env.close()

@@ -193,3 +193,38 @@ def test_act_norm_wrapper_golden(golden_dir):
         np.testing.assert_allclose(out["state"], g[f"{tag}_nstate"], rtol=RTOL, atol=ATOL)
         np.testing.assert_allclose(out["rew"], g[f"{tag}_rew"], rtol=1e-10)
         assert np.array_equal(out["done"], g[f"{tag}_done"])
+
+
+VARIANTS = {
+    "qcp_su_simple": ("qcp-su", dict(dt=0.002, max_steps=8000, simple_dynamics=True)),
+    "qcp_su_long": ("qcp-su", dict(dt=0.002, max_steps=8000, long=True)),
+    "qcp_su_tame_init": ("qcp-su", dict(dt=0.002, max_steps=8000, wild_init="False")),
+    "qbb_simple": ("qbb", dict(dt=0.01, max_steps=500, simple_dynamics=True)),
+    "qq_su_task_args": ("qq-su", dict(dt=0.004, max_steps=4000, task_args=dict(
+        state_des=np.array([0.3, -np.pi, 0.5, -0.2]), Q=np.diag([2.0, 0.5, 1e-2, 1e-3]), R=np.diag([1e-2])))),
+    "bob_task_args": ("bob", dict(dt=0.01, max_steps=500, task_args=dict(
+        state_des=np.array([0.2, 0.0, 0.0, 0.0]), Q=np.diag([1e4, 1e2, 1e2, 1e1]), R=np.diag([0.5])))),
+    "omo_inf_steps": ("omo", dict(dt=0.02, max_steps=float("inf"))),
+    "qcp_st_short_pole": ("qcp-st", dict(dt=0.01, max_steps=300, long=False, simple_dynamics=False)),
+}
+
+
+@pytest.mark.parametrize("tag", list(VARIANTS))
+def test_ctor_and_task_variants(golden_dir, tag):
+    """constructor / task options of the reference classes (simple_dynamics, long, wild_init, task_args, max_steps=inf)"""
+    g = np.load(os.path.join(golden_dir, "variants.npz"))
+    name, kw = VARIANTS[tag]
+    ref = cpu_ref.make_ref(name, **kw)
+    n = g[f"{tag}__state"].shape[0]
+    P = np.tile(g[f"{tag}__params"], (n, 1))
+    out = ref.step(g[f"{tag}__state"], g[f"{tag}__hidden"], g[f"{tag}__act"], P, g[f"{tag}__curr_step"])
+    np.testing.assert_allclose(out["state"], g[f"{tag}__nstate"], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(out["obs"], g[f"{tag}__obs"], rtol=RTOL, atol=ATOL)
+    np.testing.assert_allclose(out["rew"], g[f"{tag}__rew"], rtol=1e-10, atol=1e-300)
+    assert np.array_equal(out["done"], g[f"{tag}__done"])
+    if ref.H:
+        np.testing.assert_allclose(out["hidden"], g[f"{tag}__nhidden"], rtol=1e-10, atol=1e-12)
+    if f"{tag}__init_lo" in g.files:
+        lo, hi = ref.init_bounds(P[:1])
+        np.testing.assert_allclose(lo[0], g[f"{tag}__init_lo"], rtol=1e-14)
+        np.testing.assert_allclose(hi[0], g[f"{tag}__init_hi"], rtol=1e-14)
