@@ -133,7 +133,11 @@ int vs_version(void);
 int vs_create(int env_type, int64_t n_envs, double dt, int64_t max_steps, int device_id, const vs_task_cfg* cfg,
               vs_handle* out);
 int vs_destroy(vs_handle h);
-/* run on this hipStream_t (e.g. torch's current stream) instead of the handle's own stream; NULL restores it */
+/* Streams.  A handle launches on its own stream, created as a blocking stream (hipStreamDefault): it is implicitly
+ * ordered with the legacy default stream (torch's default "current stream"), so default-stream work may read the
+ * handle's buffers (vs_get) after a launch without further synchronisation.  A caller that runs on another,
+ * non-blocking stream (a torch side stream, a hipGraph capture stream) passes that hipStream_t here and the handle
+ * launches on it; NULL restores the own stream. */
 int vs_set_stream(vs_handle h, void* hip_stream);
 int vs_sync(vs_handle h);
 int64_t vs_n_envs(vs_handle h);
@@ -157,6 +161,25 @@ int vs_sample_params(vs_handle h, const vs_dp_spec* specs, int n_specs, uint64_t
 int vs_set_param_buffer(vs_handle h, const float* params_soa, int n_sets, int selection);
 /* toggle VS_FLAG_ACT_NORM after creation */
 int vs_set_act_norm(vs_handle h, int on);
+/* GaussianActNoiseWrapper (P/environment_wrappers/action_noise.py:38-79: act + randn * std + mean) and ActDelayWrapper
+ * (P/environment_wrappers/action_delay.py:37-112: a queue of `delay` zero actions at reset, push the commanded action,
+ * pop the oldest) fused into the step, applied after ActNormWrapper's de-normalisation and before the env's reward and
+ * action clipping -- exactly where the wrapped env's step() would see them.
+ *   delay              0 .. VS_MAX_ACT_DELAY time steps, the same for every env
+ *   noise_mean/std     A floats each (host) or NULL for none
+ *   noise_normed       the noise wrapper sits OUTSIDE ActNormWrapper: its draw is scaled by (ub - lb) / 2 of the env
+ *   noise_after_delay  the noise wrapper sits INSIDE ActDelayWrapper (noise is added to the popped action)
+ *   seed               Philox key of the noise; a draw is a pure function of (seed, global env index, episode, step)
+ * vs_step_random draws the policy's action first and then runs it through this pipeline; VS_TRAJ_ACT records the
+ * policy's action.  delay = 0 and NULL noise removes the stage. */
+#define VS_MAX_ACT_DELAY 64
+int vs_set_act_pipeline(vs_handle h, int delay, const float* noise_mean, const float* noise_std, int noise_normed,
+                        int noise_after_delay, uint64_t seed);
+/* ObsNormWrapper (P/environment_wrappers/observation_normalization.py:41-126: (obs - lb) / (ub - lb) * 2 - 1) and
+ * GaussianObsNoiseWrapper (P/environment_wrappers/observation_noise.py:38-73: obs + randn * std + mean), in any stacking
+ * order, compose to   obs' = obs * scale + shift + noise_std * z,  z ~ N(0, 1) i.i.d.   (O floats each, host, NULL =
+ * identity / none).  VS_OBS, the recorded observations and the observation vs_reset produces are the wrapped ones. */
+int vs_set_obs_pipeline(vs_handle h, const float* scale, const float* shift, const float* noise_std, uint64_t seed);
 /* DomainRandWrapperLive (P/environment_wrappers/domain_randomization.py:135-148): remember specs and redraw the
  * parameters of an env at each of its resets (vs_reset without explicit params, and auto-reset). n_specs = 0 disables. */
 int vs_set_randomizer(vs_handle h, const vs_dp_spec* specs, int n_specs);

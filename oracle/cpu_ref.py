@@ -24,6 +24,9 @@ Everything is vectorised over a leading env axis N and written op-for-op after t
                          P/tasks/final_reward.py:111-174, P/tasks/base.py:159-180
   spaces                 P/spaces/box.py:138-184, P/spaces/base.py:66-69, P/spaces/polar.py:108-113
   seeding                P/__init__.py:135-183
+  wrappers (WrappedRef)  P/environment_wrappers/base.py:288-381, action_normalization.py:66-72, action_noise.py:71-76,
+                         action_delay.py:87-112, observation_normalization.py:117-120, observation_noise.py:67-72,
+                         observation_partial.py:70-71
 
 ``dtype=np.float64`` reproduces the reference arithmetic (it computes in float64); ``dtype=np.float32`` runs the same
 expression tree in single precision and is used only to reason about done-mask flips next to a bound.
@@ -826,6 +829,71 @@ class BallOnBeamDiscRef(BallOnBeamRef):
 ENV_REFS = OrderedDict((c.name, c) for c in (OneMassOscillatorRef, BallOnBeamRef, QQubeSwingUpRef,
                                               QCartPoleSwingUpRef, QBallBalancerRef, QQubeStabRef, QCartPoleStabRef,
                                               PendulumRef, BallOnBeamDiscRef))
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# wrappers -- P/environment_wrappers/{action_normalization,action_noise,action_delay,observation_normalization,
+#             observation_noise,observation_partial}.py, stacked as EnvWrapperAct.step / EnvWrapperObs.step|reset do
+#             (P/environment_wrappers/base.py:288-381)
+# --------------------------------------------------------------------------------------------------------------------
+class WrappedRef:
+    """A stack of Pyrado wrappers around an EnvRef, restated sequentially (one stage after the other, as the Python
+    objects call each other), for N envs at once.  `stages` lists the wrappers OUTERMOST FIRST:
+
+        ("act_norm",)                      ActNormWrapper._process_act               action_normalization.py:66-72
+        ("act_noise", mean[A], std[A])     GaussianActNoiseWrapper._process_act      action_noise.py:71-76
+        ("act_delay", delay)               ActDelayWrapper.reset / _process_act      action_delay.py:87-112
+        ("obs_norm", lb[O'], ub[O'])       ObsNormWrapper._process_obs               observation_normalization.py:117-120
+        ("obs_noise", mean[O'], std[O'])   GaussianObsNoiseWrapper._process_obs      observation_noise.py:67-72
+        ("obs_partial", keep_mask[O'])     ObsPartialWrapper._process_obs            observation_partial.py:70-71
+
+    `randn(n, width)` supplies the standard-normal draws in the order the reference would make them: per step the action
+    noise wrappers outermost first, then the observation noise wrappers innermost first; per reset the observation noise
+    wrappers innermost first."""
+
+    def __init__(self, ref, stages, randn):
+        self.ref = ref
+        self.stages = list(stages)
+        self.randn = randn
+        self.queue = None
+
+    def _process_obs(self, obs):
+        for st in reversed(self.stages):  # innermost wrapper processes first
+            if st[0] == "obs_norm":
+                lb, ub = np.asarray(st[1], dtype=float), np.asarray(st[2], dtype=float)
+                obs = (obs - lb) / (ub - lb) * 2 - 1
+            elif st[0] == "obs_noise":
+                mean, std = np.asarray(st[1], dtype=float), np.asarray(st[2], dtype=float)
+                obs = obs + (self.randn(obs.shape[0], obs.shape[1]) * std + mean)
+            elif st[0] == "obs_partial":
+                obs = obs[:, np.asarray(st[1], dtype=bool)]
+        return obs
+
+    def reset(self, state):
+        """-> the observation the outermost env returns from reset(); `state`: [N, S] the inner env was reset to"""
+        n = state.shape[0]
+        self.queue = None
+        for st in self.stages:
+            if st[0] == "act_delay":
+                self.queue = [np.zeros((n, self.ref.A)) for _ in range(int(round(st[1])))]
+        return self._process_obs(self.ref.reset_obs(np.asarray(state, dtype=self.ref.dtype)))
+
+    def step(self, state, hidden, act, params, curr_step, yielded=None):
+        act = np.asarray(act, dtype=float).reshape(state.shape[0], self.ref.A)
+        _, _, alo, ahi = self.ref.bounds(np.asarray(params, dtype=self.ref.dtype))
+        for st in self.stages:  # outermost wrapper processes first
+            if st[0] == "act_norm":
+                act = alo + (act + 1) * (ahi - alo) / 2
+            elif st[0] == "act_noise":
+                act = act + (self.randn(act.shape[0], act.shape[1]) * np.asarray(st[2], dtype=float) + np.asarray(st[1], dtype=float))
+            elif st[0] == "act_delay" and int(round(st[1])) != 0:
+                self.queue.append(act)
+                act = self.queue.pop(0)
+        out = self.ref.step(state, hidden, act, params, curr_step, yielded)
+        out["act_applied"] = act
+        out["obs_inner"] = out["obs"]
+        out["obs"] = self._process_obs(out["obs"])
+        return out
 
 
 def make_ref(name, dt, max_steps, dtype=np.float64, task_args=None, **flags):

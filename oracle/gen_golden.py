@@ -426,6 +426,103 @@ def gen_variants(m=40, seed=900):
     return out
 
 
+# wrapper stacks (outermost first); the same spec builds the reference objects here, the oracle's WrappedRef and the
+# package's own wrapper classes in the tests
+CHAINS = {
+    "qq_delay3": ("qq-su", [dict(kind="act_delay", delay=3)]),
+    "qq_norm_delay_bias": ("qq-su", [dict(kind="act_norm"), dict(kind="act_delay", delay=2),
+                                     dict(kind="act_noise", mean=[0.2], std=[0.0])]),
+    "qbb_noise_over_norm": ("qbb", [dict(kind="act_noise", mean=[0.1, -0.2], std=[0.05, 0.1]), dict(kind="act_norm")]),
+    "qq_obsnorm_over_bias": ("qq-su", [
+        dict(kind="obs_norm", lb={"theta_dot": -20.0, "alpha_dot": -25.0}, ub={"theta_dot": 20.0, "alpha_dot": 35.0}),
+        dict(kind="obs_noise", mean=[0.01, -0.02, 0.03, 0.0, 0.5, -0.4], std=[0.0] * 6)]),
+    "qbb_noise_norm_partial": ("qbb", [dict(kind="obs_noise", mean=[0.0] * 6, std=[0.01, 0.02, 0.03, 0.04, 0.05, 0.06]),
+                                       dict(kind="obs_norm"), dict(kind="obs_partial", idcs=[0, 1])]),
+    "bob_partial_norm_delay": ("bob", [dict(kind="obs_partial", mask=[0, 0, 0, 1]), dict(kind="obs_norm"),
+                                       dict(kind="act_delay", delay=1), dict(kind="act_norm")]),
+    # ObsNormWrapper cannot wrap QCartPole in the reference: its reset() returns the 4-D state (Q5) -> action side only
+    "qcp_delay_over_noise": ("qcp-su", [dict(kind="act_delay", delay=2), dict(kind="act_noise", mean=[-0.3], std=[0.5])]),
+    "omo_everything": ("omo", [
+        dict(kind="obs_noise", mean=[0.0, 0.1], std=[0.02, 0.3]), dict(kind="act_delay", delay=2),
+        dict(kind="obs_norm"), dict(kind="act_noise", mean=[0.5], std=[2.0]), dict(kind="act_norm"),
+        dict(kind="obs_noise", mean=[0.05, 0.0], std=[0.01, 0.1])]),
+}
+
+
+def build_reference_chain(env, stages):
+    from pyrado.environment_wrappers.action_delay import ActDelayWrapper
+    from pyrado.environment_wrappers.action_noise import GaussianActNoiseWrapper
+    from pyrado.environment_wrappers.action_normalization import ActNormWrapper
+    from pyrado.environment_wrappers.observation_noise import GaussianObsNoiseWrapper
+    from pyrado.environment_wrappers.observation_normalization import ObsNormWrapper
+    from pyrado.environment_wrappers.observation_partial import ObsPartialWrapper
+
+    for st in reversed(stages):  # innermost first
+        k = st["kind"]
+        if k == "act_norm":
+            env = ActNormWrapper(env)
+        elif k == "act_delay":
+            env = ActDelayWrapper(env, delay=st["delay"])
+        elif k == "act_noise":
+            env = GaussianActNoiseWrapper(env, noise_mean=np.array(st["mean"]), noise_std=np.array(st["std"]))
+        elif k == "obs_norm":
+            env = ObsNormWrapper(env, explicit_lb=st.get("lb"), explicit_ub=st.get("ub"))
+        elif k == "obs_noise":
+            env = GaussianObsNoiseWrapper(env, noise_std=np.array(st["std"]), noise_mean=np.array(st["mean"]))
+        elif k == "obs_partial":
+            env = ObsPartialWrapper(env, mask=st.get("mask"), idcs=st.get("idcs"))
+        else:
+            raise ValueError(k)
+    return env
+
+
+def gen_chains(n_ep=3, T=30, seed=1200):
+    """trajectories of wrapped reference envs.  Noise: np.random.seed(base + 1000 * episode + event) right before
+    reset() (event 0) and before step t (event t + 1), so that a checker can replay the very same randn() calls."""
+    from pyrado.environment_wrappers.utils import inner_env
+
+    out = {"spec": np.array(json.dumps({k: dict(env=v[0], stages=v[1]) for k, v in CHAINS.items()}))}
+    for ci, (tag, (name, stages)) in enumerate(CHAINS.items()):
+        cls, kw = ENVS[name]
+        env = build_reference_chain(cls(**kw), stages)
+        base = inner_env(env)
+        rng = np.random.default_rng(seed + ci)
+        rec = {k: [] for k in ("s0", "h0", "obs0", "act", "obs", "rew", "done", "state", "hidden", "length")}
+        for ep in range(n_ep):
+            lo, hi = base.state_space.bound_lo, base.state_space.bound_up
+            s0 = 0.3 * rng.uniform(lo, hi)
+            np.random.seed(seed + 1000 * ep + 0)
+            obs0 = env.reset(init_state=s0.copy())
+            ep_rec = {k: [] for k in ("act", "obs", "rew", "done", "state", "hidden")}
+            h0 = get_hidden(name, base)
+            alo, ahi = env.act_space.bound_lo, env.act_space.bound_up
+            length = T
+            for t in range(T):
+                a = rng.uniform(1.2 * alo, 1.2 * ahi)
+                np.random.seed(seed + 1000 * ep + t + 1)
+                obs, rew, done, _ = env.step(a.copy())
+                for k, v in zip(ep_rec, (a, np.array(obs, dtype=np.float64), float(rew), bool(done),
+                                          np.array(base.state, dtype=np.float64), get_hidden(name, base))):
+                    ep_rec[k].append(v)
+                if done and length == T:
+                    length = t + 1
+            rec["s0"].append(s0)
+            rec["h0"].append(h0)
+            rec["obs0"].append(np.array(obs0, dtype=np.float64))
+            rec["length"].append(length)
+            for k, v in ep_rec.items():
+                rec[k].append(np.array(v))
+        for k, v in rec.items():
+            out[f"{tag}__{k}"] = np.array(v)
+        out[f"{tag}__params"] = params_to_vec(base, base.domain_param)
+        out[f"{tag}__obs_lo"] = np.array(env.obs_space.bound_lo, dtype=np.float64)
+        out[f"{tag}__obs_hi"] = np.array(env.obs_space.bound_up, dtype=np.float64)
+        out[f"{tag}__act_lo"] = np.array(env.act_space.bound_lo, dtype=np.float64)
+        out[f"{tag}__act_hi"] = np.array(env.act_space.bound_up, dtype=np.float64)
+    out["seed"] = np.array(seed)
+    return out
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     m_step = {"omo": 256, "bob": 256, "qq-su": 256, "qcp-su": 256, "qbb": 128, "qq-st": 192, "qcp-st": 192, "pend": 192,
@@ -446,6 +543,8 @@ def main():
         np.savez_compressed(os.path.join(OUT, "qbb_ik.npz"), **gen_ik())
     if force or not os.path.exists(os.path.join(OUT, "variants.npz")):
         np.savez_compressed(os.path.join(OUT, "variants.npz"), **gen_variants())
+    if force or not os.path.exists(os.path.join(OUT, "chains.npz")):
+        np.savez_compressed(os.path.join(OUT, "chains.npz"), **gen_chains())
     if force or not os.path.exists(os.path.join(OUT, "wrappers.npz")):
         np.savez_compressed(os.path.join(OUT, "wrappers.npz"), **gen_wrappers())
     with open(os.path.join(OUT, "randomizers.json"), "w") as fh:

@@ -17,8 +17,10 @@ from .exceptions import KeyErr, ShapeErr, TypeErr, ValueErr  # noqa: F401
 from .seeding import derive_seed, get_base_seed, set_seed  # noqa: F401
 from .spaces import BoxSpace, CompoundSpace, DiscreteSpace, EnvSpec, Polar2DPosVelSpace, SingularStateSpace  # noqa: F401
 from .vec_env import MixedVecSimEnv, VecSimEnv, env_dims, nominal_params, param_names  # noqa: F401
-from .wrappers import (ActNormWrapper, DomainRandWrapper, DomainRandWrapperBuffer, DomainRandWrapperLive,  # noqa: F401
-                       EnvWrapper, EnvWrapperAct, all_envs, inner_env, typed_env)
+from .wrappers import (ActDelayWrapper, ActNormWrapper, DomainRandWrapper, DomainRandWrapperBuffer,  # noqa: F401
+                       DomainRandWrapperLive, EnvWrapper, EnvWrapperAct, EnvWrapperObs, FusedChain,
+                       GaussianActNoiseWrapper, GaussianObsNoiseWrapper, ObsNormWrapper, ObsPartialWrapper, all_envs,
+                       fuse_wrappers, inner_env, typed_env)
 
 inf = float("inf")
 

@@ -12,6 +12,7 @@ ENV_TYPES = {"omo": 0, "bob": 1, "qq-su": 2, "qcp-su": 3, "qbb": 4, "qq-st": 5, 
  VS_FAILED, VS_EPSTAT_COUNT, VS_EPSTAT_RETSUM, VS_EPSTAT_LENSUM, VS_JAC_STATE, VS_JAC_REW, VS_JAC_OBS) = range(25)
 VS_FLAG_SIMPLE_DYNAMICS, VS_FLAG_LONG_POLE, VS_FLAG_ACT_NORM = 1, 2, 4
 VS_DP_NORMAL, VS_DP_UNIFORM = 0, 1
+VS_MAX_ACT_DELAY = 64
 
 
 class TaskCfg(C.Structure):
@@ -45,6 +46,9 @@ _SIGNATURES = {
     "vs_set_randomizer": (C.c_int, [_P, C.POINTER(DpSpec), C.c_int]),
     "vs_set_param_buffer": (C.c_int, [_P, _P, C.c_int, C.c_int]),
     "vs_set_act_norm": (C.c_int, [_P, C.c_int]),
+    "vs_set_act_pipeline": (C.c_int, [_P, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.c_int,
+                                      C.c_uint64]),
+    "vs_set_obs_pipeline": (C.c_int, [_P, C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_uint64]),
     "vs_reset": (C.c_int, [_P, _P, C.c_int64, C.c_int, _P, C.c_uint64]),
     "vs_set_index_offset": (C.c_int, [_P, C.c_uint32]),
     "vs_set_auto_reset": (C.c_int, [_P, C.c_int, C.c_uint64]),

@@ -13,6 +13,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/vecsim.h"
@@ -27,8 +28,26 @@ struct DrSpecs {
     vs_dp_spec s[MAXP];
 };
 
+// The cheap wrappers scripts stack around these envs, fused into the step instead of being Python objects around it:
+// GaussianActNoiseWrapper (P/environment_wrappers/action_noise.py:38-79), ActDelayWrapper (action_delay.py:37-112),
+// ObsNormWrapper (observation_normalization.py:41-126) and GaussianObsNoiseWrapper (observation_noise.py:38-73).
+// Action side, after ActNormWrapper's de-normalisation:  a -> [+ noise] -> delay ring -> [+ noise] -> env.step
+// Observation side:  obs' = obs * scale + shift + std * z   (any stack of norm / noise stages composes to this)
+struct Pipe {
+    int act_on, obs_on;
+    int delay;              // ActDelayWrapper: the action applied at step t is the one commanded at t - delay (0 before)
+    int act_noise, obs_noise;
+    int noise_normed;       // the noise wrapper sits outside ActNormWrapper: its draw is in [-1, 1] units
+    int noise_after_delay;  // the noise wrapper sits inside ActDelayWrapper
+    float a_mean[MAXA], a_std[MAXA];
+    float o_scale[MAXO], o_shift[MAXO], o_std[MAXO];
+    float* ring;            // [delay][A][ld]
+    uint64_t seed;          // noise streams: Philox(seed; env, RNG_*_NOISE, episode index << 32 | step)
+};
+
 // device pointers of one handle, passed to kernels by value
 struct Dev {
+    Pipe pipe;
     float *state, *hidden, *obs, *rew, *ret, *consts, *params, *consts_uni;
     uint8_t *done, *failed, *err, *yielded;
     int* step;
@@ -54,6 +73,75 @@ struct Dev {
     float *jac_s, *jac_r, *jac_o;  // step Jacobians (vs_step_jac), allocated on first use
     int n, ld;
 };
+
+// ------------------------------------------------------------------------------------------------- wrapper pipeline
+__device__ __forceinline__ void box_muller(uint32_t b0, uint32_t b1, float& z0, float& z1) {
+    float u1 = 1.0f - Rng::to_u01(b0);  // (0, 1]
+    float r = sqrtf(-2.0f * logf(u1)), sn, cs;
+    sincosf(TWO_PI_F * Rng::to_u01(b1), &sn, &cs);
+    z0 = r * cs;
+    z1 = r * sn;
+}
+
+// a: the action in the env's own units (after ActNormWrapper); step: curr_step of the lane before this step
+template <class E>
+__device__ __forceinline__ void pipe_act(const Dev& d, int i, uint32_t epi, int step, const float* c, float* a) {
+    static_assert(E::A <= MAXA, "action width");
+    const Pipe& p = d.pipe;
+    float nz[E::A];
+#pragma unroll
+    for (int j = 0; j < E::A; ++j) nz[j] = 0.f;
+    if (p.act_noise) {
+        uint4 b = Rng::philox(p.seed, d.idx0 + (uint32_t)i, RNG_ACT_NOISE, ((uint64_t)epi << 32) | (uint32_t)step);
+        float z[2];
+        box_muller(b.x, b.y, z[0], z[1]);
+        float lb[E::A], ub[E::A];
+        E::act_bounds(c, lb, ub);
+#pragma unroll
+        for (int j = 0; j < E::A; ++j)
+            nz[j] = (p.a_mean[j] + p.a_std[j] * z[j]) * (p.noise_normed ? 0.5f * (ub[j] - lb[j]) : 1.0f);
+    }
+    if (!p.noise_after_delay) {
+#pragma unroll
+        for (int j = 0; j < E::A; ++j) a[j] += nz[j];
+    }
+    if (p.delay > 0) {
+        // the queue of the reference starts as `delay` zero actions at reset; a ring slot is only read once the
+        // episode has written it, so nothing has to be cleared at reset
+        int slot = step % p.delay;
+#pragma unroll
+        for (int j = 0; j < E::A; ++j) {
+            float* r = p.ring + ((size_t)slot * E::A + j) * d.ld + i;
+            float prev = step >= p.delay ? *r : 0.f;
+            *r = a[j];
+            a[j] = prev;
+        }
+    }
+    if (p.noise_after_delay) {
+#pragma unroll
+        for (int j = 0; j < E::A; ++j) a[j] += nz[j];
+    }
+}
+
+// step: curr_step of the lane the observation belongs to (0 for the observation reset() returns)
+template <class E>
+__device__ __forceinline__ void pipe_obs(const Dev& d, int i, uint32_t epi, int step, const float* ob, float* out) {
+    static_assert(E::O <= MAXO, "observation width");
+    const Pipe& p = d.pipe;
+    float z[MAXO];
+#pragma unroll
+    for (int j = 0; j < MAXO; ++j) z[j] = 0.f;
+    if (p.obs_noise) {
+        Rng g(p.seed, d.idx0 + (uint32_t)i, RNG_OBS_NOISE, ((uint64_t)epi << 32) | (uint32_t)step);
+#pragma unroll
+        for (int j = 0; j < E::O; j += 2) {
+            uint32_t b0 = g.next(), b1 = g.next();
+            box_muller(b0, b1, z[j], z[j + 1]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < E::O; ++j) out[j] = fmaf(ob[j], p.o_scale[j], p.o_shift[j]) + p.o_std[j] * z[j];
+}
 
 // ---------------------------------------------------------------------------------------------------- reward / step
 // DesStateTask.step_rew / RadiallySymmDesStateTask.step_rew + the three reward functions
@@ -90,7 +178,8 @@ using StepOut = StepOutT<float>;
 // ob: observe() of the pre-step state if the caller holds it in registers (saves the trig it shares with the dynamics)
 template <class E, class R>
 __device__ __forceinline__ StepOutT<R> step_one(const Task& T, const float* c, R* s, R* h, const R* a_raw, int& step,
-                                                bool& yielded, const R* ob) {
+                                                bool& yielded, const R* ob, const Dev* dp = nullptr, int lane = 0,
+                                                uint32_t epi = 0u) {
     StepOutT<R> o;
     // ActNormWrapper._process_act (action_normalization.py:66-72), branch-free: a wave-uniform select keeps the step one
     // basic block for the scheduler
@@ -103,6 +192,9 @@ __device__ __forceinline__ StepOutT<R> step_one(const Task& T, const float* c, R
         for (int j = 0; j < E::A; ++j) {
             R m = lb[j] + (a_raw[j] + 1.0f) * (ub[j] - lb[j]) * 0.5f;
             an[j] = vsel(nrm, m, a_raw[j]);
+        }
+        if constexpr (std::is_same<R, float>::value) {
+            if (dp && dp->pipe.act_on) pipe_act<E>(*dp, lane, epi, step, c, an);  // wave-uniform branch
         }
         a_raw = an;
     }
@@ -272,7 +364,8 @@ __device__ __forceinline__ void auto_reset(const Task& T, const Dev& d, bool fin
 // ------------------------------------------------------------------------------------------------------- step kernel
 // vs_step: one fused SimPyEnv.step per lane.  AR = auto-reset of finished lanes inside the same launch.
 // No host-side counter enters the kernel: replaying a captured hipGraph of vs_step launches is safe.
-template <class E, bool UNI, bool AR>
+// PIPE: the wrapper pipeline (struct Pipe) is compiled in; the default kernels do not carry it.
+template <class E, bool UNI, bool AR, bool PIPE = false>
 __device__ __forceinline__ void step_body(const Task& T, const Dev& d, const float* __restrict__ act, long env_stride,
                                           long dim_stride, uint64_t seed, int block) {
     int i = block * BLOCK + threadIdx.x;
@@ -289,8 +382,11 @@ __device__ __forceinline__ void step_body(const Task& T, const Dev& d, const flo
     for (int j = 0; j < E::A; ++j) a[j] = valid ? act[(size_t)i * env_stride + (size_t)j * dim_stride] : 0.f;
     int step = d.step[i];
     bool yielded = E::FINAL != FINAL_NONE ? d.yielded[i] != 0 : false;
+    const bool noisy = PIPE && (d.pipe.act_noise | d.pipe.obs_noise);  // wave-uniform
+    uint32_t epi = noisy ? d.ep_idx[i] : 0u;
 
-    StepOut o = step_one<E, float>(T, c, s, h, a, step, yielded, (const float*)nullptr);
+    StepOut o = step_one<E, float>(T, c, s, h, a, step, yielded, (const float*)nullptr, PIPE ? &d : (const Dev*)nullptr,
+                                   i, epi);
 
     float ret = d.ret[i] + o.rew;
     d.rew[i] = o.rew;
@@ -315,6 +411,10 @@ __device__ __forceinline__ void step_body(const Task& T, const Dev& d, const flo
 
     float ob[E::O];
     E::observe(s, ob);
+    if (PIPE && d.pipe.obs_on) {
+        if (AR && noisy) epi = d.ep_idx[i];  // a lane that was just reset shows the first observation of its new episode
+        pipe_obs<E>(d, i, epi, step, ob, ob);
+    }
 #pragma unroll
     for (int j = 0; j < E::S; ++j) d.state[j * ld + i] = s[j];
 #pragma unroll
@@ -326,10 +426,10 @@ __device__ __forceinline__ void step_body(const Task& T, const Dev& d, const flo
     if (E::FINAL != FINAL_NONE) d.yielded[i] = yielded;
 }
 
-template <class E, bool UNI, bool AR>
+template <class E, bool UNI, bool AR, bool PIPE>
 __global__ __launch_bounds__(BLOCK) void k_step(Task T, Dev d, const float* __restrict__ act, long env_stride,
                                                 long dim_stride, uint64_t seed) {
-    step_body<E, UNI, AR>(T, d, act, env_stride, dim_stride, seed, (int)blockIdx.x);
+    step_body<E, UNI, AR, PIPE>(T, d, act, env_stride, dim_stride, seed, (int)blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------------- Jacobian kernel
@@ -411,7 +511,7 @@ __global__ __launch_bounds__(BLOCK) void k_step_jac(Task T, Dev d, const float* 
 // Without auto-reset a finished lane freezes (rollout stops at done).
 // Actions: Philox4x32-10 keyed by `seed`, counter (env, RNG_ACT, absolute step / SPB); one block feeds SPB = 4 / A
 // consecutive steps (the block boundary is wave-uniform because it depends on the launch-global step index only).
-template <class E, bool UNI, bool AR, bool REC>
+template <class E, bool UNI, bool AR, bool REC, bool PIPE = false>
 __device__ __forceinline__ void rollout_body(const Task& T, const Dev& d, int k_steps, uint64_t seed, uint64_t reset_seed,
                                              uint64_t epoch0, int block) {
     const size_t rec0 = (size_t)d.traj_t0;  // first record row of this launch (vs_set_traj_offset)
@@ -459,13 +559,21 @@ __device__ __forceinline__ void rollout_body(const Task& T, const Dev& d, int k_
         }
         if (REC) {
             size_t tb = rec0 + (size_t)t;
+            if (PIPE && d.pipe.obs_on) {  // wave-uniform; the raw observation stays in `ob` (the dynamics reuse its trig)
+                float ow[E::O];
+                pipe_obs<E>(d, i, es.epi, step, ob, ow);
 #pragma unroll
-            for (int j = 0; j < E::O; ++j) d.traj_obs[(tb * E::O + j) * ld + i] = ob[j];
+                for (int j = 0; j < E::O; ++j) d.traj_obs[(tb * E::O + j) * ld + i] = ow[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < E::O; ++j) d.traj_obs[(tb * E::O + j) * ld + i] = ob[j];
+            }
 #pragma unroll
             for (int j = 0; j < E::A; ++j) d.traj_act[(tb * E::A + j) * ld + i] = a[j];
         }
         if (!frozen) {
-            StepOut o = step_one<E, float>(T, c, s, h, a, step, yielded, REC ? (const float*)ob : (const float*)nullptr);
+            StepOut o = step_one<E, float>(T, c, s, h, a, step, yielded, REC ? (const float*)ob : (const float*)nullptr,
+                                           PIPE ? &d : (const Dev*)nullptr, i, es.epi);
             rew = o.rew;
             done = o.done;
             failed = o.failed;
@@ -501,6 +609,7 @@ __device__ __forceinline__ void rollout_body(const Task& T, const Dev& d, int k_
 #endif
     }
     if (!REC) E::observe(s, ob);
+    if (PIPE && d.pipe.obs_on) pipe_obs<E>(d, i, es.epi, step, ob, ob);
 #pragma unroll
     for (int j = 0; j < E::S; ++j) d.state[j * ld + i] = s[j];
 #pragma unroll
@@ -519,10 +628,10 @@ __device__ __forceinline__ void rollout_body(const Task& T, const Dev& d, int k_
     d.es_lensum[i] = es.lensum;
 }
 
-template <class E, bool UNI, bool AR, bool REC>
+template <class E, bool UNI, bool AR, bool REC, bool PIPE>
 __global__ __launch_bounds__(BLOCK) void k_rollout(Task T, Dev d, int k_steps, uint64_t seed, uint64_t reset_seed,
                                                    uint64_t epoch0) {
-    rollout_body<E, UNI, AR, REC>(T, d, k_steps, seed, reset_seed, epoch0, (int)blockIdx.x);
+    rollout_body<E, UNI, AR, REC, PIPE>(T, d, k_steps, seed, reset_seed, epoch0, (int)blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------------- mixed batches
@@ -647,6 +756,7 @@ __global__ __launch_bounds__(BLOCK) void k_reset(Task T, Dev d, const float* __r
         E::init_hidden(T, c, p, s, h, full_state != 0);
     }
     E::observe(s, ob);
+    if (d.pipe.obs_on) pipe_obs<E>(d, i, 1u, 0, ob, ob);  // EnvWrapperObs.reset processes the first observation too
 #pragma unroll
     for (int j = 0; j < E::S; ++j) d.state[j * ld + i] = s[j];
 #pragma unroll
@@ -672,6 +782,7 @@ __global__ __launch_bounds__(BLOCK) void k_observe(Dev d) {
 #pragma unroll
     for (int j = 0; j < E::S; ++j) s[j] = d.state[(size_t)j * d.ld + i];
     E::observe(s, ob);
+    if (d.pipe.obs_on) pipe_obs<E>(d, i, d.ep_idx[i], d.step[i], ob, ob);
 #pragma unroll
     for (int j = 0; j < E::O; ++j) d.obs[(size_t)j * d.ld + i] = ob[j];
 }
@@ -766,6 +877,7 @@ struct vs_env {
     DrSpecs* d_dr = nullptr;      // its device copy (Dev::dr)
     DrSpecs* d_specs = nullptr;   // device scratch for vs_sample_params
     float* d_pbuf = nullptr;      // DomainRandWrapperBuffer parameter sets
+    float* d_ring = nullptr;      // ActDelayWrapper ring (Pipe::ring)
     bool auto_reset = false;
     uint64_t ar_seed = 0;
     bool uniform = true;
@@ -886,9 +998,11 @@ template <class E>
 static void launch_step(vs_handle h, const float* act, long es, long ds) {
     dim3 g = grid_for(h->d.ld), b(BLOCK);
     bool uni = h->uniform && h->dr.n == 0 && h->d.pbuf_n == 0;
-#define LS(U, AR) hipLaunchKernelGGL((k_step<E, U, AR>), g, b, 0, h->stream, h->task, h->d, act, es, ds, h->ar_seed)
-    if (h->auto_reset) { if (uni) LS(true, true); else LS(false, true); }
-    else { if (uni) LS(true, false); else LS(false, false); }
+#define LS(U, AR, PI) hipLaunchKernelGGL((k_step<E, U, AR, PI>), g, b, 0, h->stream, h->task, h->d, act, es, ds, h->ar_seed)
+    if (h->d.pipe.act_on || h->d.pipe.obs_on) {  // the wrapper pipeline: per-env-constant variant only
+        if (h->auto_reset) LS(false, true, true); else LS(false, false, true);
+    } else if (h->auto_reset) { if (uni) LS(true, true, false); else LS(false, true, false); }
+    else { if (uni) LS(true, false, false); else LS(false, false, false); }
 #undef LS
 }
 
@@ -896,8 +1010,12 @@ template <class E>
 static void launch_rollout(vs_handle h, int k, uint64_t seed, uint64_t ep, bool rec) {
     bool uni = h->uniform && h->dr.n == 0;
     dim3 g = grid_for(h->d.ld), b(BLOCK);
-#define LR(U, AR, R) hipLaunchKernelGGL((k_rollout<E, U, AR, R>), g, b, 0, h->stream, h->task, h->d, k, seed, h->ar_seed, ep)
-    if (uni) {
+#define LR(U, AR, R) hipLaunchKernelGGL((k_rollout<E, U, AR, R, false>), g, b, 0, h->stream, h->task, h->d, k, seed, h->ar_seed, ep)
+#define LP(AR, R) hipLaunchKernelGGL((k_rollout<E, false, AR, R, true>), g, b, 0, h->stream, h->task, h->d, k, seed, h->ar_seed, ep)
+    if (h->d.pipe.act_on || h->d.pipe.obs_on) {
+        if (h->auto_reset) { if (rec) LP(true, true); else LP(true, false); }
+        else { if (rec) LP(false, true); else LP(false, false); }
+    } else if (uni) {
         if (h->auto_reset) { if (rec) LR(true, true, true); else LR(true, true, false); }
         else { if (rec) LR(true, false, true); else LR(true, false, false); }
     } else {
@@ -905,6 +1023,7 @@ static void launch_rollout(vs_handle h, int k, uint64_t seed, uint64_t ep, bool 
         else { if (rec) LR(false, false, true); else LR(false, false, false); }
     }
 #undef LR
+#undef LP
 }
 
 struct vs_mixed {
@@ -922,6 +1041,10 @@ static int mixed_upload(vs_mixed* m, const float* const* acts, const int64_t* en
     vs_handle h0 = m->sub[0];
     for (int q = 0; q < m->n; ++q) {
         vs_handle h = m->sub[q];
+        if (h->d.pipe.act_on || h->d.pipe.obs_on) {
+            m->err = "mixed batch: a segment carries an action/observation pipeline (single-family handles only)";
+            return VS_ERR_STATE;
+        }
         Seg& sg = m->host.s[q];
         blocks += (h->d.ld + BLOCK - 1) / BLOCK;
         sg.type = h->type;
@@ -947,7 +1070,7 @@ static int mixed_upload(vs_mixed* m, const float* const* acts, const int64_t* en
 
 extern "C" {
 
-int vs_version(void) { return 110; }
+int vs_version(void) { return 120; }
 
 int vs_env_dims(int t, int* S, int* A, int* O, int* P, int* H, int* I, int* K) {
     if (t < 0 || t >= VS_ENV_COUNT) return VS_ERR_ARG;
@@ -1014,7 +1137,10 @@ int vs_create(int env_type, int64_t n_envs, double dt, int64_t max_steps, int de
 #define CK(x) do { rc = (x); if (rc != VS_OK) { g_create_err = h->err; vs_destroy(h); return rc; } } while (0)
 #define HK(x) do { hipError_t e2 = (x); if (e2 != hipSuccess) { fail(nullptr, VS_ERR_HIP, #x, e2); vs_destroy(h); return VS_ERR_HIP; } } while (0)
     HK(hipSetDevice(device_id));
-    HK(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+    // a BLOCKING stream: it orders itself with the legacy default stream, which is where torch (and most callers) run
+    // unless told otherwise -- zero-copy views of the handle's buffers can then be read by default-stream work without
+    // an explicit sync.  Callers on other non-blocking streams hand theirs over with vs_set_stream.
+    HK(hipStreamCreateWithFlags(&h->own_stream, hipStreamDefault));
     h->stream = h->own_stream;
     Dev& d = h->d;
     d.n = (int)n_envs;
@@ -1065,6 +1191,7 @@ int vs_destroy(vs_handle h) {
     if (h->stage) (void)hipFree(h->stage);
     if (h->stage_mask) (void)hipFree(h->stage_mask);
     if (h->d_pbuf) (void)hipFree(h->d_pbuf);
+    if (h->d_ring) (void)hipFree(h->d_ring);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
     return VS_OK;
@@ -1185,6 +1312,62 @@ int vs_set_act_norm(vs_handle h, int on) {
     return VS_OK;
 }
 
+int vs_set_act_pipeline(vs_handle h, int delay, const float* noise_mean, const float* noise_std, int noise_normed,
+                        int noise_after_delay, uint64_t seed) {
+    if (!h) return VS_ERR_ARG;
+    if (delay < 0 || delay > VS_MAX_ACT_DELAY) return fail(h, VS_ERR_ARG, "vs_set_act_pipeline: delay must be in [0, VS_MAX_ACT_DELAY]");
+    const EnvInfo& ei = ENV_INFO[h->type];
+    Pipe& p = h->d.pipe;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (delay != p.delay) {
+        if (h->d_ring) { HIPCHK(h, hipFree(h->d_ring)); h->d_ring = nullptr; }
+        if (delay > 0) {
+            size_t bytes = (size_t)delay * ei.A * h->d.ld * sizeof(float);
+            HIPCHK(h, hipMalloc((void**)&h->d_ring, bytes));
+            // on the handle's stream: a null-stream memset is not ordered with kernels on a non-blocking stream
+            HIPCHK(h, hipMemsetAsync(h->d_ring, 0, bytes, h->stream));
+        }
+        p.ring = h->d_ring;
+        p.delay = delay;
+    }
+    p.act_noise = 0;
+    for (int j = 0; j < MAXA; ++j) {
+        p.a_mean[j] = (noise_mean && j < ei.A) ? noise_mean[j] : 0.f;
+        p.a_std[j] = (noise_std && j < ei.A) ? noise_std[j] : 0.f;
+        if (p.a_std[j] < 0.f || p.a_std[j] != p.a_std[j]) return fail(h, VS_ERR_ARG, "vs_set_act_pipeline: noise_std must be >= 0");
+        if (p.a_mean[j] != 0.f || p.a_std[j] != 0.f) p.act_noise = 1;
+    }
+    p.noise_normed = noise_normed != 0;
+    p.noise_after_delay = noise_after_delay != 0;
+    p.seed = seed;
+    p.act_on = p.delay > 0 || p.act_noise;
+    return VS_OK;
+}
+
+int vs_set_obs_pipeline(vs_handle h, const float* scale, const float* shift, const float* noise_std, uint64_t seed) {
+    if (!h) return VS_ERR_ARG;
+    const EnvInfo& ei = ENV_INFO[h->type];
+    Pipe& p = h->d.pipe;
+    p.obs_noise = 0;
+    bool ident = true;
+    for (int j = 0; j < MAXO; ++j) {
+        p.o_scale[j] = (scale && j < ei.O) ? scale[j] : 1.f;
+        p.o_shift[j] = (shift && j < ei.O) ? shift[j] : 0.f;
+        p.o_std[j] = (noise_std && j < ei.O) ? noise_std[j] : 0.f;
+        if (p.o_std[j] < 0.f || p.o_std[j] != p.o_std[j]) return fail(h, VS_ERR_ARG, "vs_set_obs_pipeline: noise_std must be >= 0");
+        if (p.o_std[j] != 0.f) p.obs_noise = 1;
+        if (p.o_scale[j] != 1.f || p.o_shift[j] != 0.f) ident = false;
+    }
+    p.seed = seed;
+    p.obs_on = !ident || p.obs_noise;
+    // VS_OBS is the wrapped observation from now on
+    HIPCHK(h, hipSetDevice(h->device));
+    DISPATCH_ENV(h->type, hipLaunchKernelGGL(k_observe<E>, grid_for(h->d.ld), dim3(BLOCK), 0, h->stream, h->d));
+    HIPCHK(h, hipGetLastError());
+    return VS_OK;
+}
+
 int vs_reset(vs_handle h, const float* init_state, int64_t pitch, int full, const uint8_t* mask, uint64_t seed) {
     if (!h) return VS_ERR_ARG;
     HIPCHK(h, hipSetDevice(h->device));
@@ -1242,6 +1425,8 @@ int vs_step_jac(vs_handle h, const float* actions, int64_t env_stride, int64_t d
     if (!h || !actions) return fail(h, VS_ERR_ARG, "vs_step_jac: NULL argument");
     if (!is_device_ptr(actions)) return fail(h, VS_ERR_ARG, "vs_step_jac: actions must be device memory");
     if (h->auto_reset) return fail(h, VS_ERR_STATE, "vs_step_jac: switch auto-reset off (the Jacobian of a reset is meaningless)");
+    if (h->d.pipe.act_on || h->d.pipe.obs_on)
+        return fail(h, VS_ERR_STATE, "vs_step_jac: remove the action/observation pipeline (Jacobians are those of the bare env)");
     HIPCHK(h, hipSetDevice(h->device));
     const EnvInfo& ei = ENV_INFO[h->type];
     if (!h->d.jac_s) {

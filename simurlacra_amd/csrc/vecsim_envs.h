@@ -188,7 +188,7 @@ struct Rng {
         return sqrtf(-2.0f * logf(u1)) * cosf(TWO_PI_F * u2);
     }
 };
-enum RngPurpose { RNG_ACT = 1, RNG_INIT = 2, RNG_PARAM = 3 };
+enum RngPurpose { RNG_ACT = 1, RNG_INIT = 2, RNG_PARAM = 3, RNG_ACT_NOISE = 4, RNG_OBS_NOISE = 5 };
 
 // defaults shared by the env structs (static members are inherited)
 enum FinalKind { FINAL_NONE = 0, FINAL_CONST_MALUS = 1, FINAL_STATE_TIME = 2 };

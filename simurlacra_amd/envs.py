@@ -224,16 +224,20 @@ class VecSimPyEnv(SimEnv):
     # ------------------------------------------------------------------------------------------ domain parameters
     @property
     def domain_param(self) -> dict:
-        return dict(self._domain_param)  # a copy, like the reference's getter (pysim/base.py:108-110)
+        # a copy, like the reference's getter (pysim/base.py:108-110); keys the env does not know (the wrappers park
+        # theirs here: act_delay, obs_noise_std, ...) are kept as in the reference's plain dict.update
+        return {**self._domain_param, **getattr(self, "_foreign_domain_param", {})}
 
     @domain_param.setter
     def domain_param(self, domain_param: dict):
         if not isinstance(domain_param, dict):
             raise TypeErr(given=domain_param, expected_type=dict)
-        unknown = [k for k in domain_param if k not in self._domain_param]
-        if unknown:
-            raise ValueErr(msg=f"unsupported domain parameter(s) {unknown} for env {self.name}")
-        self._domain_param.update({k: float(np.asarray(v).reshape(-1)[0]) for k, v in domain_param.items()})
+        known = {k: v for k, v in domain_param.items() if k in self._domain_param}
+        if len(known) < len(domain_param):
+            foreign = dict(getattr(self, "_foreign_domain_param", {}))
+            foreign.update({k: v for k, v in domain_param.items() if k not in known})
+            self._foreign_domain_param = foreign
+        self._domain_param.update({k: float(np.asarray(v).reshape(-1)[0]) for k, v in known.items()})
         if self._vec is not None:
             self._vec.set_params_uniform(self._domain_param)  # _calc_constants + spaces + task.reset on the device
 

@@ -25,7 +25,7 @@ from . import _lib as L
 from .exceptions import TypeErr, ValueErr
 from .policies import DummyPolicy
 from .seeding import derive_seed, get_base_seed, set_seed
-from .wrappers import ActNormWrapper, DomainRandWrapperBuffer, DomainRandWrapperLive, inner_env, typed_env
+from .wrappers import DomainRandWrapperBuffer, DomainRandWrapperLive, fuse_wrappers, inner_env, typed_env
 
 NO_SEED = object()
 
@@ -200,7 +200,7 @@ class ParallelRolloutSampler:
         v.set_randomizer([])
         v.set_param_buffer(None)
         v.set_params_uniform(base.domain_param)
-        v.set_act_norm(typed_env(self.env, ActNormWrapper) is not None)  # the policy then acts in [-1, 1]
+        self._fc = fuse_wrappers(self.env)  # ActNorm / act noise / act delay / obs norm / obs noise / partial obs
         return v
 
     def _run_batch(self, work, first_index, eval):
@@ -208,8 +208,21 @@ class ParallelRolloutSampler:
         import torch
 
         n = len(work)
-        base = inner_env(self.env)
         v = self._vec_for(n)
+        # the library's kernels and the torch ops that read its buffers must be ordered: on torch's legacy default stream
+        # (pointer 0) the handle's own blocking stream is ordered with it implicitly, any other current stream is handed
+        # to the handle
+        v.use_stream(torch.cuda.current_stream(v.device).cuda_stream or None)
+        try:
+            return self._run_batch_on_stream(v, work, first_index, eval)
+        finally:
+            v.use_stream(None)
+
+    def _run_batch_on_stream(self, v, work, first_index, eval):
+        import torch
+
+        n = len(work)
+        base = inner_env(self.env)
         max_steps = base.max_steps
         if max_steps == math.inf:
             raise ValueErr(msg="ParallelRolloutSampler needs a finite env.max_steps")
@@ -220,6 +233,7 @@ class ParallelRolloutSampler:
         lane_key = key
         v.set_index_offset(first_index)
         v.seek_random(0)
+        self._fc.apply(v, seed=lane_key)  # the wrappers of the chain, fused into the kernels; noise keyed per sample() call
         dps = [w[1] for w in work]
         live = typed_env(self.env, DomainRandWrapperLive)
         if any(d is not None for d in dps):
@@ -251,7 +265,11 @@ class ParallelRolloutSampler:
                     arr[j] = np.asarray(s, dtype=np.float32).reshape(-1)
             v.reset(init_state=arr, mask=mask, seed=lane_key)
         dev = f"cuda:{v.device}"
-        obs_t = v.tensor(L.VS_OBS)[:, :n]
+        obs_full = v.tensor(L.VS_OBS)[:, :n]
+        keep = None if self._fc.keep.all() else torch.from_numpy(np.flatnonzero(self._fc.keep)).to(dev)
+
+        def visible(x, dim):  # ObsPartialWrapper: the rows of the observation the outermost env reports
+            return x if keep is None else x.index_select(dim, keep)
         done_t, st_t = v.tensor(L.VS_DONE)[0, :n], v.tensor(L.VS_STATE)[:, :n]
         rew_t = v.tensor(L.VS_REW)[0, :n]
         use_fused = isinstance(self.policy, DummyPolicy)
@@ -271,20 +289,19 @@ class ParallelRolloutSampler:
                     break
             v.set_traj_offset(0)
             tt = v.traj_tensors()
-            obs_T, act_T = tt["obs"][:t, :, :n], tt["act"][:t, :, :n]  # [T, dim, n]
+            obs_T, act_T = visible(tt["obs"][:t, :, :n], 1), tt["act"][:t, :, :n]  # [T, dim, n]
             rew_T, done_T = tt["rew"][:t, :n], tt["done"][:t, :n].bool()  # [T, n]
         else:
             policy = self.policy.to(dev) if hasattr(self.policy, "to") else self.policy
             if hasattr(policy, "eval"):
                 policy.eval() if eval else policy.train()
-            v.use_stream(torch.cuda.current_stream().cuda_stream)
             obs_rec, act_rec, rew_rec, done_rec = [], [], [], []
             alive = torch.ones(n, dtype=torch.bool, device=dev)
             with torch.no_grad():
                 while t < T_cap:
-                    obs = obs_t.t()
-                    act = policy(obs).to(torch.float32).reshape(n, A).contiguous()
-                    obs_rec.append(obs_t.clone())
+                    obs_now = visible(obs_full, 0)
+                    act = policy(obs_now.t()).to(torch.float32).reshape(n, A).contiguous()
+                    obs_rec.append(obs_now.clone() if keep is None else obs_now)
                     act_rec.append(act.t())
                     v.step(act)
                     rew_rec.append(rew_t.clone())
@@ -294,7 +311,6 @@ class ParallelRolloutSampler:
                         alive &= ~torch.stack(done_rec[-32:]).bool().any(dim=0)
                         if not bool(alive.any()):
                             break
-            v.use_stream(None)
             obs_T, act_T = torch.stack(obs_rec), torch.stack(act_rec)  # [T, dim, n]
             rew_T, done_T = torch.stack(rew_rec), torch.stack(done_rec).bool()
         v.raise_on_error()
@@ -307,7 +323,7 @@ class ParallelRolloutSampler:
         tgrid = torch.arange(T + 1, device=dev)[None, :]
         mask = tgrid[:, :T] < length[:, None]  # [n, T]
         mask_o = tgrid <= length[:, None]  # [n, T + 1]: one observation more than steps
-        obs_ext = torch.cat([obs_T, obs_t[None]], dim=0)  # the row after the last step is the current observation
+        obs_ext = torch.cat([obs_T, visible(obs_full, 0)[None]], dim=0)  # the row after the last step: the current observation
         obs_p = obs_ext.permute(2, 0, 1)[mask_o].cpu().numpy()
         act_p = act_T.permute(2, 0, 1)[mask].cpu().numpy()
         rew_p = rew_T.t()[mask].cpu().numpy()

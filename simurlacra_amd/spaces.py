@@ -32,6 +32,22 @@ class Space:
     def flat_dim(self) -> int:
         return int(np.prod(self.shape))
 
+    def create_mask(self, *idcs) -> np.ndarray:
+        """boolean mask with True at the given indices or labels (P/spaces/base.py:103-136)"""
+        mask = np.zeros(self.shape, dtype=np.bool_)
+        if len(idcs) == 1 and hasattr(idcs[0], "__iter__") and not isinstance(idcs[0], str):
+            idcs = idcs[0]
+        for idx in idcs:
+            if isinstance(idx, str):
+                hits = [i for i, lab in np.ndenumerate(self.labels) if lab == idx]
+                if not hits:
+                    raise ValueErr(msg=f"Label {idx} not found in {self}")
+                idx = hits[0]
+            if np.all(mask[idx] == 1):
+                raise ValueErr(msg=f"Duplicate index {idx}")
+            mask[idx] = 1
+        return mask
+
     def copy(self):
         return deepcopy(self)
 

@@ -259,6 +259,35 @@ class VecSimEnv:
         """Fuse ActNormWrapper into the kernels: incoming actions are in [-1, 1]."""
         self._check(self._lib.vs_set_act_norm(self._h, int(bool(on))), "vs_set_act_norm")
 
+    def _fvec(self, x, width, what):
+        if x is None:
+            return None
+        arr = np.ascontiguousarray(np.broadcast_to(np.asarray(x, dtype=np.float32), (width,)))
+        if not np.isfinite(arr).all():
+            raise ValueErr(msg=f"{what} must be finite")
+        return arr.ctypes.data_as(C.POINTER(C.c_float)), arr  # keep the array alive
+
+    def set_act_pipeline(self, delay=0, noise_mean=None, noise_std=None, noise_normed=False, noise_after_delay=False,
+                         seed=0):
+        """Fuse GaussianActNoiseWrapper / ActDelayWrapper into the kernels (vs_set_act_pipeline).  The policy's action is
+        de-normalised (ActNormWrapper, if fused), then  [+ noise] -> delay queue -> [+ noise]  -> env.step."""
+        delay = int(round(delay))  # ActDelayWrapper.delay rounds (action_delay.py:57-62)
+        if not 0 <= delay <= L.VS_MAX_ACT_DELAY:
+            raise ValueErr(given=delay, ge_constraint="0", le_constraint=str(L.VS_MAX_ACT_DELAY))
+        A = self.dims["A"]
+        m, s = self._fvec(noise_mean, A, "noise_mean"), self._fvec(noise_std, A, "noise_std")
+        self._check(self._lib.vs_set_act_pipeline(self._h, delay, m[0] if m else None, s[0] if s else None,
+                                                  int(bool(noise_normed)), int(bool(noise_after_delay)),
+                                                  C.c_uint64(seed & (2 ** 64 - 1))), "vs_set_act_pipeline")
+
+    def set_obs_pipeline(self, scale=None, shift=None, noise_std=None, seed=0):
+        """Fuse ObsNormWrapper / GaussianObsNoiseWrapper into the kernels: obs' = obs * scale + shift + noise_std * z
+        (vs_set_obs_pipeline).  `compose_obs_stages` turns a wrapper stack into these three vectors."""
+        O = self.dims["O"]
+        a, b, s = self._fvec(scale, O, "scale"), self._fvec(shift, O, "shift"), self._fvec(noise_std, O, "noise_std")
+        self._check(self._lib.vs_set_obs_pipeline(self._h, a[0] if a else None, b[0] if b else None, s[0] if s else None,
+                                                  C.c_uint64(seed & (2 ** 64 - 1))), "vs_set_obs_pipeline")
+
     # ------------------------------------------------------------------------------------------------ reset / step
     def reset(self, init_state=None, mask=None, seed=0):
         """SimPyEnv.reset for all (masked) envs. init_state: None (sample init space) or [N, I] / [N, S]."""

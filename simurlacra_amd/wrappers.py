@@ -312,3 +312,271 @@ class ActNormWrapper(EnvWrapperAct):
 
     def device_fuse(self, on: bool = True):
         self.vec.set_act_norm(on)
+
+
+class EnvWrapperObs(EnvWrapper):
+    """Base of the wrappers that modify the observation (P/environment_wrappers/base.py:333-381)."""
+
+    def _process_obs(self, obs: np.ndarray) -> np.ndarray:
+        raise NotImplementedError
+
+    def _process_obs_space(self, space):
+        return space
+
+    @property
+    def obs_space(self):
+        return self._process_obs_space(self._wrapped_env.obs_space)
+
+    def reset(self, init_state: np.ndarray = None, domain_param: dict = None) -> np.ndarray:
+        return self._process_obs(super().reset(init_state=init_state, domain_param=domain_param))
+
+    def step(self, act: np.ndarray) -> tuple:
+        obs, rew, done, info = super().step(act)
+        return self._process_obs(obs), rew, done, info
+
+
+class GaussianActNoiseWrapper(EnvWrapperAct):
+    """act + randn * std + mean (P/environment_wrappers/action_noise.py:38-79); NumPy global RNG on an env object,
+    Philox on the device once `fuse_wrappers` has moved it into the kernels."""
+
+    def __init__(self, wrapped_env, noise_mean=None, noise_std=None):
+        super().__init__(wrapped_env)
+        shape = self.act_space.shape
+        self._mean = np.zeros(shape) if noise_mean is None else np.array(noise_mean)
+        self._std = np.zeros(shape) if noise_std is None else np.array(noise_std)
+        for v in (self._mean, self._std):
+            if not v.shape == shape:
+                raise ShapeErr(given=v, expected_match=self.act_space)
+
+    def _process_act(self, act: np.ndarray) -> np.ndarray:
+        noise = np.random.randn(*self.act_space.shape) * self._std + self._mean
+        return act + noise
+
+    def _set_wrapper_domain_param(self, domain_param: dict):
+        domain_param["act_noise_mean"] = self._mean
+        domain_param["act_noise_std"] = self._std
+
+    def _get_wrapper_domain_param(self, domain_param: dict):
+        # the reference stores these under other attribute names than _process_act reads (action_noise.py:92-101), so a
+        # domain-param update never changes the noise that is applied; kept
+        if "act_noise_mean" in domain_param:
+            self._noise_mean = np.array(domain_param["act_noise_mean"])
+            if not self._noise_mean.shape == self.act_space.shape:
+                raise ShapeErr(given=self._noise_mean, expected_match=self.act_space)
+        if "act_noise_std" in domain_param:
+            self._noise_std = np.array(domain_param["act_noise_std"])
+            if not self._noise_std.shape == self.act_space.shape:
+                raise ShapeErr(given=self._noise_std, expected_match=self.act_space)
+
+
+class ActDelayWrapper(EnvWrapperAct):
+    """Delays the actions by a fixed number of steps; the queue starts as `delay` zero actions at every reset
+    (P/environment_wrappers/action_delay.py:37-112)."""
+
+    def __init__(self, wrapped_env, delay: int = 0):
+        super().__init__(wrapped_env)
+        self._delay = delay
+        self._act_queue = []
+
+    @property
+    def delay(self) -> int:
+        if isinstance(self._delay, np.ndarray):
+            return np.round(self._delay)
+        return round(self._delay)
+
+    @delay.setter
+    def delay(self, delay: int):
+        if not delay >= 0:
+            raise ValueErr(given=delay, ge_constraint="0")
+        self._delay = round(delay)
+
+    def _set_wrapper_domain_param(self, domain_param: dict):
+        domain_param["act_delay"] = self._delay
+
+    def _get_wrapper_domain_param(self, domain_param: dict):
+        self._delay = domain_param.get("act_delay", self._delay)
+
+    def reset(self, init_state: np.ndarray = None, domain_param: dict = None) -> np.ndarray:
+        init_obs = super().reset(init_state=init_state, domain_param=domain_param)
+        self._act_queue = [np.zeros(self.act_space.shape)] * int(self.delay)
+        return init_obs
+
+    def _process_act(self, act: np.ndarray) -> np.ndarray:
+        if self.delay != 0:
+            self._act_queue.append(act)
+            act = self._act_queue.pop(0)
+        return act
+
+
+class GaussianObsNoiseWrapper(EnvWrapperObs):
+    """obs + randn * std + mean (P/environment_wrappers/observation_noise.py:38-95)"""
+
+    def __init__(self, wrapped_env, noise_std, noise_mean=None):
+        super().__init__(wrapped_env)
+        self._std = np.array(noise_std)
+        if not self._std.shape == self.obs_space.shape:
+            raise ShapeErr(given=self._std, expected_match=self.obs_space)
+        if noise_mean is not None:
+            self._mean = np.array(noise_mean)
+            if not self._mean.shape == self.obs_space.shape:
+                raise ShapeErr(given=self._mean, expected_match=self.obs_space)
+        else:
+            self._mean = np.zeros(self.obs_space.shape)
+
+    def _process_obs(self, obs: np.ndarray) -> np.ndarray:
+        noise = np.random.randn(*self.obs_space.shape) * self._std + self._mean
+        return obs + noise
+
+    def _set_wrapper_domain_param(self, domain_param: dict):
+        domain_param["obs_noise_mean"] = self._mean
+        domain_param["obs_noise_std"] = self._std
+
+    def _get_wrapper_domain_param(self, domain_param: dict):
+        if "obs_noise_mean" in domain_param:
+            self._mean = np.array(domain_param["obs_noise_mean"])
+            assert self._mean.shape == self.obs_space.shape
+        if "obs_noise_std" in domain_param:
+            self._std = np.array(domain_param["obs_noise_std"])
+            assert self._std.shape == self.obs_space.shape
+
+
+class ObsNormWrapper(EnvWrapperObs):
+    """(obs - lb) / (ub - lb) * 2 - 1 with optional per-label overrides of infinite bounds
+    (P/environment_wrappers/observation_normalization.py:41-126)"""
+
+    def __init__(self, wrapped_env, explicit_lb=None, explicit_ub=None):
+        super().__init__(wrapped_env)
+        self.explicit_lb = explicit_lb
+        self.explicit_ub = explicit_ub
+        wos = self.wrapped_env.obs_space
+        lb, ub = wos.bounds
+        self.ov_lb = ObsNormWrapper.override_bounds(lb, self.explicit_lb, wos.labels)
+        self.ov_ub = ObsNormWrapper.override_bounds(ub, self.explicit_ub, wos.labels)
+        if any(self.ov_lb == -np.inf):
+            raise ValueErr(msg=f"At least one element of the lower bounds is (negative) infinite:\n"
+                               f"(overwritten) bound: {self.ov_lb}\nnames: {wos.labels}")
+        if any(self.ov_ub == np.inf):
+            raise ValueErr(msg=f"At least one element of the upper bound is (positive) infinite:\n"
+                               f"(overwritten) bound: {self.ov_ub}\nnames: {wos.labels}")
+
+    @staticmethod
+    def override_bounds(bounds: np.ndarray, override, names: np.ndarray) -> np.ndarray:
+        if not override:
+            return bounds
+        bc = bounds.copy()
+        for idx, name in np.ndenumerate(names):
+            ov = override.get(name)
+            if ov is not None:
+                bc[idx] = ov
+            elif np.isinf(bc[idx]):
+                raise ValueErr(msg=f"The entry {name} of a bound is infinite and not overwritten. Cannot apply normalization!")
+        return bc
+
+    def _process_obs(self, obs: np.ndarray) -> np.ndarray:
+        return (obs - self.ov_lb) / (self.ov_ub - self.ov_lb) * 2 - 1
+
+    def _process_obs_space(self, space):
+        from .spaces import BoxSpace
+
+        if not isinstance(space, BoxSpace):
+            raise NotImplementedError("Only implemented ObsNormWrapper._process_obs_space() for BoxSpace!")
+        return BoxSpace(-np.ones(space.shape), np.ones(space.shape), labels=space.labels)
+
+
+class ObsPartialWrapper(EnvWrapperObs):
+    """Drops (or keeps) selected observation entries (P/environment_wrappers/observation_partial.py:36-75)"""
+
+    def __init__(self, wrapped_env, mask: list = None, idcs: list = None, keep_selected: bool = False):
+        super().__init__(wrapped_env)
+        if mask is not None:
+            mask = np.array(mask, dtype=bool)
+            if not mask.shape == wrapped_env.obs_space.shape:
+                raise ShapeErr(given=mask, expected_match=wrapped_env.obs_space)
+        else:
+            assert idcs is not None, "Either mask or indices must be specified"
+            mask = wrapped_env.obs_space.create_mask(idcs)
+        self.keep_mask = mask if keep_selected else np.logical_not(mask)
+
+    def _process_obs(self, obs: np.ndarray) -> np.ndarray:
+        return obs[self.keep_mask]
+
+    def _process_obs_space(self, space):
+        return space.subspace(self.keep_mask)
+
+
+# ---------------------------------------------------------------------------------------------- chain -> kernel pipeline
+class FusedChain:
+    """What a stack of wrappers around a pysim env amounts to, in the terms of vs_set_act_norm / vs_set_act_pipeline /
+    vs_set_obs_pipeline.  `keep` selects the rows of VS_OBS the outermost env reports (ObsPartialWrapper)."""
+
+    def __init__(self, O, A):
+        self.act_norm = False
+        self.delay = 0
+        self.noise_mean, self.noise_std = np.zeros(A), np.zeros(A)
+        self.noise_normed = self.noise_after_delay = False
+        self.scale, self.shift, self.var = np.ones(O), np.zeros(O), np.zeros(O)
+        self.keep = np.ones(O, dtype=bool)
+
+    @property
+    def obs_std(self):
+        return np.sqrt(self.var)
+
+    def apply(self, vec, seed=0):
+        vec.set_act_norm(self.act_norm)
+        vec.set_act_pipeline(self.delay, self.noise_mean, self.noise_std, self.noise_normed, self.noise_after_delay,
+                             seed=seed ^ 0x2545F4914F6CDD1D)
+        vec.set_obs_pipeline(self.scale, self.shift, self.obs_std, seed=seed ^ 0x9E3779B97F4A7C15)
+
+
+def fuse_wrappers(env) -> FusedChain:
+    """Walk the wrapper chain of `env` and express it as the kernels' fixed pipeline.
+
+    Action side (outermost wrapper acts first):  ActNormWrapper, GaussianActNoiseWrapper, ActDelayWrapper in any order, at
+    most one of each.  A delay wrapper commutes with the normalisation (the queue's zero action is the centre of the
+    symmetric action boxes of these envs); a noise wrapper outside the normalisation draws in [-1, 1] units
+    (`noise_normed`), one inside the delay adds to the delayed action (`noise_after_delay`).
+    Observation side (innermost acts first): any stack of ObsNormWrapper / GaussianObsNoiseWrapper / ObsPartialWrapper;
+    affine stages compose, independent Gaussian stages add their variances.
+    Raises NotImplementedError for wrappers the kernels do not express."""
+    base = inner_env(env)
+    O, A = base.obs_space.flat_dim, base.act_space.flat_dim
+    fc = FusedChain(O, A)
+    chain = [e for e in all_envs(env) if isinstance(e, EnvWrapper)]  # outermost first
+    seen_norm = seen_delay = seen_noise = False
+    for w in chain:  # action side: outermost first
+        if isinstance(w, ActNormWrapper):
+            if seen_norm:
+                raise NotImplementedError("two ActNormWrappers in one chain")
+            seen_norm = fc.act_norm = True
+        elif isinstance(w, ActDelayWrapper):
+            if seen_delay:
+                raise NotImplementedError("two ActDelayWrappers in one chain")
+            seen_delay = True
+            fc.delay = int(w.delay)
+        elif isinstance(w, GaussianActNoiseWrapper):
+            if seen_noise:
+                raise NotImplementedError("two GaussianActNoiseWrappers in one chain")
+            seen_noise = True
+            fc.noise_mean, fc.noise_std = w._mean.astype(np.float64), w._std.astype(np.float64)
+            fc.noise_normed = not seen_norm and any(isinstance(x, ActNormWrapper) for x in all_envs(w.wrapped_env))
+            fc.noise_after_delay = seen_delay
+        elif isinstance(w, EnvWrapperAct):
+            raise NotImplementedError(f"{type(w).__name__} is not fused into the kernels")
+    idx = np.arange(O)  # rows of VS_OBS that are still visible
+    for w in reversed(chain):  # observation side: innermost first
+        if isinstance(w, ObsPartialWrapper):
+            idx = idx[w.keep_mask]
+        elif isinstance(w, ObsNormWrapper):
+            k = 2.0 / (w.ov_ub - w.ov_lb)
+            b = -w.ov_lb * k - 1.0
+            fc.scale[idx] *= k
+            fc.shift[idx] = fc.shift[idx] * k + b
+            fc.var[idx] *= k * k
+        elif isinstance(w, GaussianObsNoiseWrapper):
+            fc.shift[idx] += w._mean
+            fc.var[idx] += w._std ** 2
+        elif isinstance(w, EnvWrapperObs):
+            raise NotImplementedError(f"{type(w).__name__} is not fused into the kernels")
+    fc.keep = np.zeros(O, dtype=bool)
+    fc.keep[idx] = True
+    return fc
