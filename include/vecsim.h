@@ -102,6 +102,10 @@ typedef struct vs_task_cfg {
  * (P/domain_randomization/domain_parameter.py:104-203) */
 #define VS_DP_NORMAL 0  /* NormalDomainParam(mean, std)       spread = std */
 #define VS_DP_UNIFORM 1 /* UniformDomainParam(mean, halfspan) spread = halfspan */
+#define VS_DP_BERNOULLI 2 /* BernoulliDomainParam(val_0, val_1, prob_1) (domain_parameter.py:248-311):
+                           * mean = val_0, spread = val_1, aux = prob_1 */
+/* MultivariateNormalDomainParam (domain_parameter.py:206-245) of dimension 1 is VS_DP_NORMAL with spread = sqrt(cov);
+ * higher dimensions put a vector under ONE parameter name, which no pysim env accepts */
 typedef struct vs_dp_spec {
     int32_t param_index; /* row in VS_PARAMS */
     int32_t kind;        /* VS_DP_* */
@@ -109,6 +113,8 @@ typedef struct vs_dp_spec {
     float spread;
     float clip_lo;       /* -INFINITY for none */
     float clip_up;       /* +INFINITY for none */
+    float aux;           /* VS_DP_BERNOULLI: prob_1 */
+    int32_t roundint;    /* DomainParam(roundint=True): round half to even after clipping (domain_parameter.py:127-129) */
 } vs_dp_spec;
 
 typedef struct vs_env* vs_handle;

@@ -523,6 +523,31 @@ def gen_chains(n_ep=3, T=30, seed=1200):
     return out
 
 
+DP_CASES = [
+    ("BernoulliDomainParam", dict(name="mass", val_0=1.0, val_1=3.0, prob_1=0.3, clip_up=2.5)),
+    ("BernoulliDomainParam", dict(name="stiffness", val_0=20.4, val_1=41.6, prob_1=0.7, roundint=True)),
+    ("MultivariateNormalDomainParam", dict(name="damping", mean=[0.5], cov=[[0.04]], clip_lo=0.3)),
+    ("NormalDomainParam", dict(name="stiffness", mean=30.0, std=4.0, roundint=True)),
+    ("UniformDomainParam", dict(name="mass", mean=1.0, halfspan=0.5, clip_lo=0.8, clip_up=1.3)),
+]
+
+
+def gen_domain_param_samples(n=24):
+    """draws of the reference's DomainParam classes under torch.manual_seed: the host classes of the package make the very
+    same torch calls and must reproduce them bit for bit"""
+    from pyrado.domain_randomization import domain_parameter as dpm
+
+    out = []
+    for i, (cls, kw) in enumerate(DP_CASES):
+        torch.manual_seed(4000 + i)
+        dp = getattr(dpm, cls)(**kw)
+        smp = dp.sample(n)
+        out.append(dict(cls=cls, kwargs=kw, seed=4000 + i, dtype=str(smp[0].dtype),
+                        samples=[np.asarray(t.detach().numpy(), dtype=np.float64).reshape(-1).tolist() for t in smp],
+                        mean=np.asarray(dp.mean, dtype=np.float64).reshape(-1).tolist(), fields=dp.get_field_names()))
+    return out
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     m_step = {"omo": 256, "bob": 256, "qq-su": 256, "qcp-su": 256, "qbb": 128, "qq-st": 192, "qcp-st": 192, "pend": 192,
@@ -547,6 +572,8 @@ def main():
         np.savez_compressed(os.path.join(OUT, "chains.npz"), **gen_chains())
     if force or not os.path.exists(os.path.join(OUT, "wrappers.npz")):
         np.savez_compressed(os.path.join(OUT, "wrappers.npz"), **gen_wrappers())
+    with open(os.path.join(OUT, "domain_params.json"), "w") as fh:
+        json.dump(gen_domain_param_samples(), fh, indent=1, sort_keys=True)
     with open(os.path.join(OUT, "randomizers.json"), "w") as fh:
         json.dump(gen_randomizer_tables(), fh, indent=1, sort_keys=True)
     # seed KAT straight from the reference function (table also in Pyrado/tests/test_set_seed.py:35-54)

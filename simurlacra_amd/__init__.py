@@ -7,7 +7,8 @@ reference's Python interface for that path (same class names, arguments and erro
 back to a CPU implementation: without the built library or without a GPU the constructors raise.
 """
 from . import _lib  # noqa: F401
-from .domain_randomization import (DomainParam, DomainRandomizer, NormalDomainParam, UniformDomainParam,  # noqa: F401
+from .domain_randomization import (BernoulliDomainParam, DomainParam, DomainRandomizer,  # noqa: F401
+                                   MultivariateNormalDomainParam, NormalDomainParam, UniformDomainParam,
                                    create_conservative_randomizer, create_default_randomizer,
                                    create_zero_var_randomizer)
 from .envs import (ENV_CLASSES, BallOnBeamDiscSim, BallOnBeamSim, OneMassOscillatorSim, PendulumSim,  # noqa: F401

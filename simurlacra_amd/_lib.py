@@ -11,7 +11,7 @@ ENV_TYPES = {"omo": 0, "bob": 1, "qq-su": 2, "qcp-su": 3, "qbb": 4, "qq-st": 5, 
  VS_EP_RETURNS, VS_EP_LENGTHS, VS_EP_ENVIDX, VS_EP_COUNT, VS_TRAJ_OBS, VS_TRAJ_ACT, VS_TRAJ_REW, VS_TRAJ_DONE,
  VS_FAILED, VS_EPSTAT_COUNT, VS_EPSTAT_RETSUM, VS_EPSTAT_LENSUM, VS_JAC_STATE, VS_JAC_REW, VS_JAC_OBS) = range(25)
 VS_FLAG_SIMPLE_DYNAMICS, VS_FLAG_LONG_POLE, VS_FLAG_ACT_NORM = 1, 2, 4
-VS_DP_NORMAL, VS_DP_UNIFORM = 0, 1
+VS_DP_NORMAL, VS_DP_UNIFORM, VS_DP_BERNOULLI = 0, 1, 2
 VS_MAX_ACT_DELAY = 64
 
 
@@ -23,7 +23,7 @@ class TaskCfg(C.Structure):
 
 class DpSpec(C.Structure):
     _fields_ = [("param_index", C.c_int32), ("kind", C.c_int32), ("mean", C.c_float), ("spread", C.c_float),
-                ("clip_lo", C.c_float), ("clip_up", C.c_float)]
+                ("clip_lo", C.c_float), ("clip_up", C.c_float), ("aux", C.c_float), ("roundint", C.c_int32)]
 
 
 _P = C.c_void_p

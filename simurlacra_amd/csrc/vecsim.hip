@@ -263,9 +263,12 @@ __device__ __forceinline__ void draw_params(const DrSpecs* dr, Rng& g, float* p)
     int n = dr->n;
     for (int q = 0; q < n; ++q) {
         const vs_dp_spec sp = dr->s[q];
-        float v = sp.kind == VS_DP_NORMAL ? sp.mean + sp.spread * g.normal()
-                                          : g.uniform(sp.mean - sp.spread, sp.mean + sp.spread);
+        float v;
+        if (sp.kind == VS_DP_NORMAL) v = sp.mean + sp.spread * g.normal();
+        else if (sp.kind == VS_DP_UNIFORM) v = g.uniform(sp.mean - sp.spread, sp.mean + sp.spread);
+        else v = g.u01() < sp.aux ? sp.spread : sp.mean;  // Bernoulli(prob_1): val_1 with probability prob_1, else val_0
         v = fminf(fmaxf(v, sp.clip_lo), sp.clip_up);
+        if (sp.roundint) v = rintf(v);  // torch.round: half to even
 #pragma unroll
         for (int k = 0; k < E::P; ++k)
             if (k == sp.param_index) p[k] = v;
@@ -987,8 +990,10 @@ static int check_specs(vs_handle h, const vs_dp_spec* specs, int n, DrSpecs* out
     out->n = n;
     for (int q = 0; q < n; ++q) {
         if (specs[q].param_index < 0 || specs[q].param_index >= ei.P) return fail(h, VS_ERR_ARG, "spec param_index out of range");
-        if (specs[q].kind != VS_DP_NORMAL && specs[q].kind != VS_DP_UNIFORM) return fail(h, VS_ERR_ARG, "spec kind must be VS_DP_NORMAL or VS_DP_UNIFORM");
-        if (!(specs[q].spread >= 0.f)) return fail(h, VS_ERR_ARG, "spec spread must be >= 0");
+        const int kind = specs[q].kind;
+        if (kind != VS_DP_NORMAL && kind != VS_DP_UNIFORM && kind != VS_DP_BERNOULLI) return fail(h, VS_ERR_ARG, "spec kind must be VS_DP_NORMAL, VS_DP_UNIFORM or VS_DP_BERNOULLI");
+        if (kind != VS_DP_BERNOULLI && !(specs[q].spread >= 0.f)) return fail(h, VS_ERR_ARG, "spec spread must be >= 0");
+        if (kind == VS_DP_BERNOULLI && !(specs[q].aux >= 0.f && specs[q].aux <= 1.f)) return fail(h, VS_ERR_ARG, "spec aux (prob_1) must be in [0, 1]");
         out->s[q] = specs[q];
     }
     return VS_OK;

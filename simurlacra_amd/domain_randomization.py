@@ -14,7 +14,7 @@ from typing import List, Optional, Union
 
 import numpy as np
 
-from .exceptions import KeyErr, TypeErr, ValueErr
+from .exceptions import KeyErr, ShapeErr, TypeErr, ValueErr
 
 inf = float("inf")
 
@@ -97,6 +97,70 @@ class NormalDomainParam(DomainParam):
         return ["name", "mean", "std", "clip_lo", "clip_up", "roundint"]
 
 
+class MultivariateNormalDomainParam(DomainParam):
+    """domain_parameter.py:206-245.  One name, a vector-valued sample: for the scalar parameters of the pysim envs only
+    dimension 1 is meaningful (and is what `device_specs` accepts)."""
+
+    def __init__(self, mean, cov, **kwargs):
+        import torch
+
+        super().__init__(**kwargs)
+        self.mean = torch.as_tensor(mean, dtype=torch.get_default_dtype()).view(-1)
+        self.cov = torch.as_tensor(cov, dtype=torch.get_default_dtype())
+        if not self.cov.ndim == 2:
+            raise ShapeErr(msg="The covariance needs to be given as a matrix!")
+        self._make_distr()
+
+    def _make_distr(self):
+        from torch.distributions.multivariate_normal import MultivariateNormal
+
+        self.distr = MultivariateNormal(self.mean, self.cov, validate_args=True)
+
+    def get_field_names(self):
+        return ["name", "mean", "cov", "clip_lo", "clip_up", "roundint"]
+
+    def adapt(self, domain_distr_param: str, domain_distr_param_value):
+        if domain_distr_param == "cov" and domain_distr_param_value < 0:
+            raise ValueErr(given_name="cov", ge_constraint="0")
+        super().adapt(domain_distr_param, domain_distr_param_value)
+
+
+class BernoulliDomainParam(DomainParam):
+    """val_1 with probability prob_1, else val_0 (domain_parameter.py:248-311)"""
+
+    def __init__(self, val_0, val_1, prob_1: float, **kwargs):
+        super().__init__(**kwargs)
+        self.val_0 = val_0
+        self.val_1 = val_1
+        self.prob_1 = prob_1
+        self.mean = val_0 * (1 - prob_1) + val_1 * prob_1
+        self._make_distr()
+
+    def _make_distr(self):
+        from torch.distributions.bernoulli import Bernoulli
+
+        self.distr = Bernoulli(self.prob_1, validate_args=True)
+
+    def get_field_names(self):
+        return ["name", "mean", "val_0", "val_1", "prob_1", "clip_lo", "clip_up", "roundint"]
+
+    def sample(self, num_samples: int = 1) -> list:
+        import torch
+
+        if not isinstance(num_samples, int):
+            raise TypeErr(given=num_samples, expected_type=int)
+        if num_samples <= 0:
+            raise ValueErr(given=num_samples, g_constraint="0")
+        if self.distr is None:
+            raise RuntimeError("Trying to sample a domain parameter without a specified distribution!")
+        t = self.distr.sample(sample_shape=torch.Size([num_samples]))
+        t = (torch.ones_like(t) - t) * self.val_0 + t * self.val_1
+        t = torch.clamp(t, self.clip_lo, self.clip_up)
+        if self.roundint:
+            t = torch.round(t).to(torch.int32)
+        return list(t)
+
+
 class DomainRandomizer:
     def __init__(self, *domain_params: DomainParam):
         self.domain_params = []
@@ -161,15 +225,25 @@ class DomainRandomizer:
         return DomainRandomizer(*[deepcopy(dp) for dp in self.domain_params if dp.name in names])
 
     def device_specs(self) -> list:
-        """[(name, 'normal'|'uniform', mean, spread, clip_lo, clip_up)] for vs_sample_params / vs_set_randomizer"""
+        """[(name, kind, mean, spread, clip_lo, clip_up, aux, roundint)] for vs_sample_params / vs_set_randomizer
+        (kinds and field meanings: include/vecsim.h, vs_dp_spec)"""
         out = []
         for dp in self.domain_params:
+            tail = (float(dp.clip_lo), float(dp.clip_up))
             if isinstance(dp, NormalDomainParam):
-                out.append((dp.name, "normal", float(dp.mean), float(dp.std), float(dp.clip_lo), float(dp.clip_up)))
+                out.append((dp.name, "normal", float(dp.mean), float(dp.std)) + tail + (0.0, bool(dp.roundint)))
             elif isinstance(dp, UniformDomainParam):
-                out.append((dp.name, "uniform", float(dp.mean), float(dp.halfspan), float(dp.clip_lo), float(dp.clip_up)))
+                out.append((dp.name, "uniform", float(dp.mean), float(dp.halfspan)) + tail + (0.0, bool(dp.roundint)))
+            elif isinstance(dp, BernoulliDomainParam):
+                out.append((dp.name, "bernoulli", float(dp.val_0), float(dp.val_1)) + tail + (float(dp.prob_1), bool(dp.roundint)))
+            elif isinstance(dp, MultivariateNormalDomainParam):
+                if dp.mean.numel() != 1:
+                    raise NotImplementedError("a MultivariateNormalDomainParam of dimension > 1 puts a vector under one "
+                                              "parameter name; the pysim envs only have scalar parameters")
+                out.append((dp.name, "normal", float(dp.mean[0]), float(dp.cov[0, 0]) ** 0.5) + tail + (0.0, bool(dp.roundint)))
             else:
-                raise TypeErr(given=dp, expected_type=(NormalDomainParam, UniformDomainParam))
+                raise TypeErr(given=dp, expected_type=(NormalDomainParam, UniformDomainParam, BernoulliDomainParam,
+                                                       MultivariateNormalDomainParam))
         return out
 
 

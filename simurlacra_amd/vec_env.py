@@ -207,18 +207,27 @@ class VecSimEnv:
         self._check(self._lib.vs_set_params_uniform(self._h, arr), "vs_set_params_uniform")
 
     def _specs(self, specs):
-        """specs: iterable of (name, kind 'normal'|'uniform', mean, spread, clip_lo, clip_up) or objects with those attrs"""
+        """specs: iterable of (name, kind, mean, spread, clip_lo, clip_up[, aux, roundint]) with kind 'normal' (spread =
+        std), 'uniform' (spread = halfspan) or 'bernoulli' (mean = val_0, spread = val_1, aux = prob_1), or DomainParam
+        objects (DomainRandomizer.device_specs() does the conversion)"""
+        kinds = {"normal": L.VS_DP_NORMAL, "uniform": L.VS_DP_UNIFORM, "bernoulli": L.VS_DP_BERNOULLI}
         rows = []
         for s in specs:
             if not isinstance(s, (tuple, list)):
-                kind = "normal" if hasattr(s, "std") else "uniform"
-                s = (s.name, kind, s.mean, getattr(s, "std", None) if kind == "normal" else s.halfspan,
-                     s.clip_lo, s.clip_up)
-            name, kind, mean, spread, lo, hi = s
+                from .domain_randomization import DomainRandomizer
+
+                s = DomainRandomizer(s).device_specs()[0]
+            name, kind, mean, spread, lo, hi = s[:6]
+            aux = float(s[6]) if len(s) > 6 else 0.0
+            rnd = int(bool(s[7])) if len(s) > 7 else 0
             if name not in self.param_names:
                 raise ValueErr(msg=f"unsupported domain parameter {name!r} for env {self.name}")
-            rows.append(L.DpSpec(self.param_names.index(name), L.VS_DP_NORMAL if kind == "normal" else L.VS_DP_UNIFORM,
-                                 float(mean), float(spread), float(lo), float(hi)))
+            if kind not in kinds:
+                raise ValueErr(given=kind, eq_constraint="normal, uniform or bernoulli")
+            if kind == "bernoulli" and not 0.0 <= aux <= 1.0:
+                raise ValueErr(given=aux, ge_constraint="0", le_constraint="1")
+            rows.append(L.DpSpec(self.param_names.index(name), kinds[kind], float(mean), float(spread), float(lo),
+                                 float(hi), aux, rnd))
         arr = (L.DpSpec * max(len(rows), 1))(*rows)
         return arr, len(rows)
 

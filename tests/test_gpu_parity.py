@@ -813,3 +813,48 @@ def test_ctor_and_task_variants(vs, golden_dir):
             assert ((s0 >= lo - eps) & (s0 <= hi + eps)).all(), tag
         assert env.error_count() == 0
         env.close()
+
+
+def test_bernoulli_rounded_and_1d_multivariate_params_on_device(vs):
+    """vs_sample_params with the remaining DomainParam kinds (domain_parameter.py:206-311): Bernoulli(val_0, val_1, prob_1),
+    roundint, MultivariateNormal of dimension 1; the live randomizer redraws them at auto-resets"""
+    L = vs._lib
+    n = 65536
+    env = vs.VecSimEnv("omo", n, dt=0.02, max_steps=8)
+    rz = vs.DomainRandomizer(
+        vs.BernoulliDomainParam(name="mass", val_0=1.0, val_1=3.0, prob_1=0.3, clip_up=2.5),
+        vs.NormalDomainParam(name="stiffness", mean=30.0, std=4.0, roundint=True),
+        vs.MultivariateNormalDomainParam(name="damping", mean=[0.5], cov=[[0.04]], clip_lo=0.3))
+    env.sample_params(rz.device_specs(), seed=21)
+    P = env.get(L.VS_PARAMS).astype(np.float64)
+    assert set(np.unique(P[:, 0])) == {1.0, 2.5}  # val_1 = 3 clipped to 2.5
+    assert abs((P[:, 0] == 2.5).mean() - 0.3) < 0.01
+    assert np.array_equal(P[:, 1], np.rint(P[:, 1])) and abs(P[:, 1].mean() - 30.0) < 0.1
+    assert abs(P[:, 1].std() - np.sqrt(16.0 + 1.0 / 12.0)) < 0.1  # rounding adds the variance of U(-1/2, 1/2)
+    free = P[:, 2] > np.float64(np.float32(0.3))
+    assert (P[:, 2] >= np.float32(0.3)).all() and abs(free.mean() - 0.8413) < 0.01  # P(z > -1)
+    assert abs(np.median(P[:, 2]) - 0.5) < 0.005
+    # derived constants and spaces follow (act bound = stiffness)
+    ref = cpu_ref.make_ref("omo", dt=0.02, max_steps=8)
+    _, _, alo, ahi = ref.bounds(P)
+    assert np.array_equal(ahi[:, 0], P[:, 1])
+    # same seed -> same draw; objects are accepted in place of tuples
+    env2 = vs.VecSimEnv("omo", n, dt=0.02, max_steps=8)
+    env2.sample_params(rz.domain_params, seed=21)
+    assert np.array_equal(env2.get(L.VS_PARAMS), env.get(L.VS_PARAMS))
+    # live randomisation: every auto-reset redraws
+    env.set_randomizer(rz.device_specs())
+    env.set_auto_reset(True, seed=5)
+    env.reset(seed=1)
+    p0 = env.get(L.VS_PARAMS).copy()
+    env.step_random(8, seed=2)  # every lane times out once
+    p1 = env.get(L.VS_PARAMS)
+    assert (env.episode_stats()[0] == 1).all()
+    assert 0.3 < (p0[:, 0] != p1[:, 0]).mean() < 0.55  # 2 * 0.3 * 0.7 = 0.42 of the Bernoulli draws flip
+    assert set(np.unique(p1[:, 0])) == {1.0, 2.5} and np.array_equal(p1[:, 1], np.rint(p1[:, 1]))
+    with pytest.raises(vs.ValueErr):
+        env.sample_params([("mass", "bernoulli", 1.0, 2.0, -np.inf, np.inf, 1.5, False)])
+    with pytest.raises(vs.ValueErr):
+        env.sample_params([("mass", "poisson", 1.0, 2.0, -np.inf, np.inf)])
+    env.close()
+    env2.close()
