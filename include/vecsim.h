@@ -64,9 +64,16 @@ enum vs_buffer {
     VS_EP_LENGTHS = 11,/* i32 [ep_cap] completed-episode lengths */
     VS_EP_ENVIDX = 12, /* i32 [ep_cap] env index of each completed episode */
     VS_EP_COUNT = 13,  /* u32 [1]      number of episodes appended since vs_clear_episodes */
-    VS_TRAJ_OBS = 14,  /* f32 [T][O][ld] recorded by vs_step_random(record=1): obs BEFORE each step */
-    VS_TRAJ_ACT = 15,  /* f32 [T][A][ld] raw (unclipped) actions */
-    VS_TRAJ_REW = 16,  /* f32 [T][ld] */
+    VS_TRAJ_REC = 14,  /* f32 [T][F * ld], F = O + A + 1: the records of vs_step_random(record=1), one per env and step:
+                        * [obs BEFORE the step (O) | raw (unclipped) action of the policy (A) | reward].  Row t holds the
+                        * F floats of every env split into planes of 4, 2 and 1 floats per env (F = 4 nq + 2 h2 + h1):
+                        *   plane q < nq : f32 [ld][4] at float offset 4 ld q          <- record[4q .. 4q+3]
+                        *   2-wide plane : f32 [ld][2] at 4 ld nq (if h2)              <- record[4nq], record[4nq+1]
+                        *   1-wide plane : f32 [ld]    at (4 nq + 2 h2) ld (if h1)     <- record[F-1]
+                        * so that a wavefront writes each plane with one dwordx4 / x2 / x1 store per lane, contiguously
+                        * (vs_traj_layout reports nq, h2, h1). */
+    VS_TRAJ_RESERVED_15 = 15,
+    VS_TRAJ_RESERVED_16 = 16,
     VS_TRAJ_DONE = 17, /* u8  [T][ld] */
     VS_FAILED = 18,    /* u8  [ld]     Task.has_failed(state) of the last step   P/tasks/base.py:159-167 */
     VS_EPSTAT_COUNT = 19,  /* u32 [ld]  completed episodes per env since vs_clear_episodes */
@@ -129,6 +136,8 @@ const char* vs_env_name(int env_type);
 const char* vs_param_name(int env_type, int i);
 /* nominal domain parameters (get_nominal_domain_param; qcp honours VS_FLAG_LONG_POLE); out has P floats */
 int vs_nominal_params(int env_type, int flags, float* out);
+/* plane decomposition of a VS_TRAJ_REC row (see vs_buffer): F = O + A + 1 = 4 * nq + 2 * h2 + h1 */
+int vs_traj_layout(int env_type, int* F, int* nq, int* h2, int* h1);
 /* library / ABI version */
 int vs_version(void);
 
@@ -176,7 +185,7 @@ int vs_set_act_norm(vs_handle h, int on);
  *   noise_normed       the noise wrapper sits OUTSIDE ActNormWrapper: its draw is scaled by (ub - lb) / 2 of the env
  *   noise_after_delay  the noise wrapper sits INSIDE ActDelayWrapper (noise is added to the popped action)
  *   seed               Philox key of the noise; a draw is a pure function of (seed, global env index, episode, step)
- * vs_step_random draws the policy's action first and then runs it through this pipeline; VS_TRAJ_ACT records the
+ * vs_step_random draws the policy's action first and then runs it through this pipeline; the record holds the
  * policy's action.  delay = 0 and NULL noise removes the stage. */
 #define VS_MAX_ACT_DELAY 64
 int vs_set_act_pipeline(vs_handle h, int delay, const float* noise_mean, const float* noise_std, int noise_normed,

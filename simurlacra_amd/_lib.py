@@ -8,7 +8,7 @@ LIB_PATH = os.environ.get("VS_LIB_PATH") or os.path.join(_HERE, "csrc", "libvecs
 VS_OK, VS_ERR_ARG, VS_ERR_HIP, VS_ERR_STATE, VS_ERR_NAN = 0, -1, -2, -3, -4
 ENV_TYPES = {"omo": 0, "bob": 1, "qq-su": 2, "qcp-su": 3, "qbb": 4, "qq-st": 5, "qcp-st": 6, "pend": 7, "bob-d": 8}
 (VS_STATE, VS_OBS, VS_REW, VS_DONE, VS_HIDDEN, VS_STEPCOUNT, VS_ERRFLAG, VS_RETURNS, VS_PARAMS, VS_CONSTS,
- VS_EP_RETURNS, VS_EP_LENGTHS, VS_EP_ENVIDX, VS_EP_COUNT, VS_TRAJ_OBS, VS_TRAJ_ACT, VS_TRAJ_REW, VS_TRAJ_DONE,
+ VS_EP_RETURNS, VS_EP_LENGTHS, VS_EP_ENVIDX, VS_EP_COUNT, VS_TRAJ_REC, _VS_RESERVED_15, _VS_RESERVED_16, VS_TRAJ_DONE,
  VS_FAILED, VS_EPSTAT_COUNT, VS_EPSTAT_RETSUM, VS_EPSTAT_LENSUM, VS_JAC_STATE, VS_JAC_REW, VS_JAC_OBS) = range(25)
 VS_FLAG_SIMPLE_DYNAMICS, VS_FLAG_LONG_POLE, VS_FLAG_ACT_NORM = 1, 2, 4
 VS_DP_NORMAL, VS_DP_UNIFORM, VS_DP_BERNOULLI = 0, 1, 2
@@ -29,6 +29,7 @@ class DpSpec(C.Structure):
 _P = C.c_void_p
 _SIGNATURES = {
     "vs_version": (C.c_int, []),
+    "vs_traj_layout": (C.c_int, [C.c_int] + [C.POINTER(C.c_int)] * 4),
     "vs_env_dims": (C.c_int, [C.c_int] + [C.POINTER(C.c_int)] * 7),
     "vs_env_name": (C.c_char_p, [C.c_int]),
     "vs_param_name": (C.c_char_p, [C.c_int, C.c_int]),

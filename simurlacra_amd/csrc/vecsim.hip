@@ -67,7 +67,7 @@ struct Dev {
     int *ep_len, *ep_env;
     unsigned* ep_count;
     unsigned ep_cap;
-    float *traj_obs, *traj_act, *traj_rew;
+    float* traj_rec;     // packed per-step records, see store_record
     uint8_t* traj_done;
     int traj_t0;  // record row offset of the next vs_step_random(record = 1)
     float *jac_s, *jac_r, *jac_o;  // step Jacobians (vs_step_jac), allocated on first use
@@ -508,6 +508,34 @@ __global__ __launch_bounds__(BLOCK) void k_step_jac(Task T, Dev d, const float* 
     if (E::FINAL != FINAL_NONE) d.yielded[i] = yielded;
 }
 
+// ---------------------------------------------------------------------------------------------------- step records
+// One env step is recorded as F = O + A + 1 floats  [obs (before the step) | action of the policy | reward].
+// A step's records are stored as planes of 4, 2 or 1 floats per env -- F = 4 * NQ + 2 * H2 + H1 -- each plane [ld][w]:
+// a lane writes its w floats with ONE dwordx4 / dwordx2 / dword store and a wave writes 64 * 4 * w contiguous bytes.
+// QQube: 8 floats = 2 stores instead of 8 (and one address computation instead of eight); no padding for any family.
+// Row t of the buffer starts at float offset t * F * ld; plane q at  4 * ld * q  (then the 2-wide, then the 1-wide plane).
+template <class E>
+struct Rec {
+    static constexpr int F = E::O + E::A + 1;
+    static constexpr int NQ = F / 4, H2 = (F % 4) >= 2 ? 1 : 0, H1 = F % 2;
+};
+template <class E>
+__device__ __forceinline__ void store_record(float* __restrict__ row, size_t ld, int i, const float* ob, const float* a,
+                                             float rew) {
+    using R = Rec<E>;
+    float v[R::F];
+#pragma unroll
+    for (int j = 0; j < E::O; ++j) v[j] = ob[j];
+#pragma unroll
+    for (int j = 0; j < E::A; ++j) v[E::O + j] = a[j];
+    v[R::F - 1] = rew;
+#pragma unroll
+    for (int q = 0; q < R::NQ; ++q)
+        reinterpret_cast<float4*>(row + (size_t)q * 4 * ld)[i] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+    if (R::H2) reinterpret_cast<float2*>(row + (size_t)R::NQ * 4 * ld)[i] = make_float2(v[4 * R::NQ], v[4 * R::NQ + 1]);
+    if (R::H1) row[((size_t)R::NQ * 4 + R::H2 * 2) * ld + i] = v[R::F - 1];
+}
+
 // ---------------------------------------------------------------------------------------------------- rollout kernel
 // vs_step_random: rollout() with DummyPolicy (rollout.py:185-239, dummy.py:77-84) -- k env steps per launch, state,
 // hidden state and constants stay in registers; only the per-step records stream to HBM when REC.
@@ -560,19 +588,14 @@ __device__ __forceinline__ void rollout_body(const Task& T, const Dev& d, int k_
             bool nrm = (T.flags & VS_FLAG_ACT_NORM) != 0;  // the policy then acts in the wrapper's space [-1, 1]
             a[j] = E::sample_action(c, nrm ? -1.0f : alo[j], nrm ? 1.0f : ahi[j], Rng::to_u01(bits), j);  // act_space.sample_uniform()
         }
+        float ow[E::O];  // the observation as recorded: wrapped when the pipeline is on (the raw one stays in `ob`)
         if (REC) {
-            size_t tb = rec0 + (size_t)t;
-            if (PIPE && d.pipe.obs_on) {  // wave-uniform; the raw observation stays in `ob` (the dynamics reuse its trig)
-                float ow[E::O];
+            if (PIPE && d.pipe.obs_on) {  // wave-uniform
                 pipe_obs<E>(d, i, es.epi, step, ob, ow);
-#pragma unroll
-                for (int j = 0; j < E::O; ++j) d.traj_obs[(tb * E::O + j) * ld + i] = ow[j];
             } else {
 #pragma unroll
-                for (int j = 0; j < E::O; ++j) d.traj_obs[(tb * E::O + j) * ld + i] = ob[j];
+                for (int j = 0; j < E::O; ++j) ow[j] = ob[j];
             }
-#pragma unroll
-            for (int j = 0; j < E::A; ++j) d.traj_act[(tb * E::A + j) * ld + i] = a[j];
         }
         if (!frozen) {
             StepOut o = step_one<E, float>(T, c, s, h, a, step, yielded, REC ? (const float*)ob : (const float*)nullptr,
@@ -586,7 +609,7 @@ __device__ __forceinline__ void rollout_body(const Task& T, const Dev& d, int k_
             rew = 0.f;
         }
         if (REC) {
-            d.traj_rew[(rec0 + (size_t)t) * ld + i] = rew;
+            store_record<E>(d.traj_rec + (rec0 + (size_t)t) * Rec<E>::F * ld, ld, i, ow, a, rew);
             d.traj_done[(rec0 + (size_t)t) * ld + i] = done;
         }
         bool fin = done && valid && !frozen;
@@ -1075,7 +1098,17 @@ static int mixed_upload(vs_mixed* m, const float* const* acts, const int64_t* en
 
 extern "C" {
 
-int vs_version(void) { return 120; }
+int vs_version(void) { return 130; }
+
+int vs_traj_layout(int t, int* F, int* nq, int* h2, int* h1) {
+    if (t < 0 || t >= VS_ENV_COUNT) return VS_ERR_ARG;
+    const int f = ENV_INFO[t].O + ENV_INFO[t].A + 1;
+    if (F) *F = f;
+    if (nq) *nq = f / 4;
+    if (h2) *h2 = (f % 4) >= 2 ? 1 : 0;
+    if (h1) *h1 = f % 2;
+    return VS_OK;
+}
 
 int vs_env_dims(int t, int* S, int* A, int* O, int* P, int* H, int* I, int* K) {
     if (t < 0 || t >= VS_ENV_COUNT) return VS_ERR_ARG;
@@ -1459,9 +1492,7 @@ int vs_set_traj_capacity(vs_handle h, int t_max) {
     size_t ld = d.ld;
     // old buffers stay in h->allocs until destroy (capacity only grows a handful of times)
     int rc;
-    if ((rc = dalloc(h, &d.traj_obs, (size_t)t_max * ei.O * ld))) return rc;
-    if ((rc = dalloc(h, &d.traj_act, (size_t)t_max * ei.A * ld))) return rc;
-    if ((rc = dalloc(h, &d.traj_rew, (size_t)t_max * ld))) return rc;
+    if ((rc = dalloc(h, &d.traj_rec, (size_t)t_max * (ei.O + ei.A + 1) * ld))) return rc;
     if ((rc = dalloc(h, &d.traj_done, (size_t)t_max * ld))) return rc;
     h->traj_cap = t_max;
     return VS_OK;
@@ -1606,9 +1637,7 @@ static bool buf_info(vs_handle h, int which, void** p, size_t* bytes) {
         case VS_EP_LENGTHS: *p = d.ep_len; *bytes = (size_t)d.ep_cap * 4; return true;
         case VS_EP_ENVIDX: *p = d.ep_env; *bytes = (size_t)d.ep_cap * 4; return true;
         case VS_EP_COUNT: *p = d.ep_count; *bytes = 4; return true;
-        case VS_TRAJ_OBS: *p = d.traj_obs; *bytes = (size_t)h->traj_cap * ei.O * ld * 4; return true;
-        case VS_TRAJ_ACT: *p = d.traj_act; *bytes = (size_t)h->traj_cap * ei.A * ld * 4; return true;
-        case VS_TRAJ_REW: *p = d.traj_rew; *bytes = (size_t)h->traj_cap * ld * 4; return true;
+        case VS_TRAJ_REC: *p = d.traj_rec; *bytes = (size_t)h->traj_cap * (ei.O + ei.A + 1) * ld * 4; return true;
         case VS_TRAJ_DONE: *p = d.traj_done; *bytes = (size_t)h->traj_cap * ld; return true;
         case VS_FAILED: *p = d.failed; *bytes = ld; return true;
         case VS_EPSTAT_COUNT: *p = d.es_count; *bytes = ld * 4; return true;

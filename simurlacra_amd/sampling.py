@@ -288,9 +288,9 @@ class ParallelRolloutSampler:
                 if bool(done_t.bool().all()):  # one scalar sync per launch
                     break
             v.set_traj_offset(0)
-            tt = v.traj_tensors()
-            obs_T, act_T = visible(tt["obs"][:t, :, :n], 1), tt["act"][:t, :, :n]  # [T, dim, n]
-            rew_T, done_T = tt["rew"][:t, :n], tt["done"][:t, :n].bool()  # [T, n]
+            tt = v.traj_tensors(t, n)
+            obs_T, act_T = visible(tt["obs"], 2), tt["act"]  # [T, n, dim]
+            rew_T, done_T = tt["rew"], tt["done"].bool()  # [T, n]
         else:
             policy = self.policy.to(dev) if hasattr(self.policy, "to") else self.policy
             if hasattr(policy, "eval"):
@@ -299,10 +299,10 @@ class ParallelRolloutSampler:
             alive = torch.ones(n, dtype=torch.bool, device=dev)
             with torch.no_grad():
                 while t < T_cap:
-                    obs_now = visible(obs_full, 0)
-                    act = policy(obs_now.t()).to(torch.float32).reshape(n, A).contiguous()
-                    obs_rec.append(obs_now.clone() if keep is None else obs_now)
-                    act_rec.append(act.t())
+                    obs_now = visible(obs_full, 0).t().contiguous()  # [n, O']: what the policy sees and what is recorded
+                    act = policy(obs_now).to(torch.float32).reshape(n, A).contiguous()
+                    obs_rec.append(obs_now)
+                    act_rec.append(act)
                     v.step(act)
                     rew_rec.append(rew_t.clone())
                     done_rec.append(done_t.clone())
@@ -311,7 +311,7 @@ class ParallelRolloutSampler:
                         alive &= ~torch.stack(done_rec[-32:]).bool().any(dim=0)
                         if not bool(alive.any()):
                             break
-            obs_T, act_T = torch.stack(obs_rec), torch.stack(act_rec)  # [T, dim, n]
+            obs_T, act_T = torch.stack(obs_rec), torch.stack(act_rec)  # [T, n, dim]
             rew_T, done_T = torch.stack(rew_rec), torch.stack(done_rec).bool()
         v.raise_on_error()
         # ---- split into rollouts on the device: rollout j = steps 0 .. first done of lane j, packed lane-major ----
@@ -323,9 +323,9 @@ class ParallelRolloutSampler:
         tgrid = torch.arange(T + 1, device=dev)[None, :]
         mask = tgrid[:, :T] < length[:, None]  # [n, T]
         mask_o = tgrid <= length[:, None]  # [n, T + 1]: one observation more than steps
-        obs_ext = torch.cat([obs_T, visible(obs_full, 0)[None]], dim=0)  # the row after the last step: the current observation
-        obs_p = obs_ext.permute(2, 0, 1)[mask_o].cpu().numpy()
-        act_p = act_T.permute(2, 0, 1)[mask].cpu().numpy()
+        obs_ext = torch.cat([obs_T, visible(obs_full, 0).t()[None]], dim=0)  # the row after the last step: the current obs
+        obs_p = obs_ext.permute(1, 0, 2)[mask_o].cpu().numpy()
+        act_p = act_T.permute(1, 0, 2)[mask].cpu().numpy()
         rew_p = rew_T.t()[mask].cpu().numpy()
         done_last = done_T[first, ar].cpu().numpy()
         length_h = length.cpu().numpy()

@@ -376,17 +376,35 @@ class VecSimEnv:
         self._check(self._lib.vs_set_traj_offset(self._h, int(t0)), "vs_set_traj_offset")
         self._traj_t0 = int(t0)
 
-    def traj_tensors(self):
-        """zero-copy torch views of the record buffers: obs [T, O, ld], act [T, A, ld], rew [T, ld], done [T, ld]"""
+    def traj_layout(self):
+        """(F, nq, h2, h1): a record is F = O + A + 1 floats [obs | act | rew], stored as nq planes of 4, h2 of 2 and h1 of 1
+        floats per env (include/vecsim.h, VS_TRAJ_REC)"""
+        v = [C.c_int() for _ in range(4)]
+        self._check(self._lib.vs_traj_layout(L.ENV_TYPES[self.name], *[C.byref(x) for x in v]), "vs_traj_layout")
+        return tuple(x.value for x in v)
+
+    def traj_tensors(self, k_steps=None, n=None):
+        """The recorded steps as torch tensors on the device: dict(obs [T, n, O], act [T, n, A], rew [T, n], done [T, n] u8).
+        `rec` ([T, n, F], one gather of the record planes) is the only copy; obs / act / rew are views of it, done is a
+        view of the library's buffer.  The caller orders its stream with the handle's (see vs_set_stream)."""
         import torch
 
-        out = {}
-        for key, which, rows, dt in (("obs", L.VS_TRAJ_OBS, self.dims["O"], "<f4"), ("act", L.VS_TRAJ_ACT, self.dims["A"], "<f4"),
-                                     ("rew", L.VS_TRAJ_REW, 1, "<f4"), ("done", L.VS_TRAJ_DONE, 1, "|u1")):
-            ptr = self._lib.vs_get(self._h, which)
-            shape = (self._traj_cap, rows, self.ld) if key in ("obs", "act") else (self._traj_cap, self.ld)
-            out[key] = torch.as_tensor(_DevArray(ptr, shape, dt, self), device=f"cuda:{self.device}")
-        return out
+        T = self._traj_cap if k_steps is None else int(k_steps)
+        n = self.n_envs if n is None else int(n)
+        F, nq, h2, h1 = self.traj_layout()
+        O, A, ld = self.dims["O"], self.dims["A"], self.ld
+        dev = f"cuda:{self.device}"
+        ptr = self._lib.vs_get(self._h, L.VS_TRAJ_REC)
+        rows = torch.as_tensor(_DevArray(ptr, (self._traj_cap, F * ld), "<f4", self), device=dev)[:T]
+        parts, off = [], 0
+        for w, count in ((4, nq), (2, h2), (1, h1)):
+            for _ in range(count):
+                parts.append(rows[:, off:off + w * ld].view(T, ld, w)[:, :n])
+                off += w * ld
+        rec = torch.cat(parts, dim=2)  # [T, n, F]
+        dptr = self._lib.vs_get(self._h, L.VS_TRAJ_DONE)
+        done = torch.as_tensor(_DevArray(dptr, (self._traj_cap, ld), "|u1", self), device=dev)[:T, :n]
+        return dict(rec=rec, obs=rec[..., :O], act=rec[..., O:O + A], rew=rec[..., F - 1], done=done)
 
     def step_random(self, k_steps=1, seed=0, record=False):
         if record and getattr(self, "_traj_t0", 0) + k_steps > self._traj_cap:
@@ -445,18 +463,9 @@ class VecSimEnv:
 
     def traj(self, k_steps):
         """Host copies of the recorded trajectory buffers of the last step_random(record=True): dict of [T, N, dim]"""
-        import torch
-
-        out = {}
-        for key, which, rows, dt in (("obs", L.VS_TRAJ_OBS, self.dims["O"], "<f4"), ("act", L.VS_TRAJ_ACT, self.dims["A"], "<f4"),
-                                     ("rew", L.VS_TRAJ_REW, 1, "<f4"), ("done", L.VS_TRAJ_DONE, 1, "|u1")):
-            ptr = self._lib.vs_get(self._h, which)
-            arr = _DevArray(ptr, (self._traj_cap, rows, self.ld), dt, self)
-            self.sync()
-            t = torch.as_tensor(arr, device=f"cuda:{self.device}")[:k_steps, :, : self.n_envs].permute(0, 2, 1)
-            t = t.cpu().numpy()
-            out[key] = t if rows > 1 or key in ("obs", "act") else t[..., 0]
-        return out
+        self.sync()
+        tt = self.traj_tensors(k_steps)
+        return {k: tt[k].cpu().numpy() for k in ("obs", "act", "rew", "done")}
 
     def set_episode_log(self, on=True):
         """Opt-in per-episode log (ballot-compacted ring). Off by default: see include/vecsim.h."""
