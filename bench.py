@@ -252,7 +252,7 @@ def main():
             ms = env.time_step_kernel(iters=20, k_steps=chunk, record=bool(args.record))
             b_per = bytes_fused_step(d, chunk, bool(args.record))
             units = n * chunk
-            kname = "k_rollout"
+            kname = env.rollout_variant()
         else:
             act = (torch.rand(n, d["A"], device=f"cuda:{local_rank}") * 2 - 1) * act_hi
             torch.cuda.synchronize()
@@ -292,8 +292,10 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes/launch (PMC)",
                          "traffic_source": traffic_src, "alg_bytes_per_launch": b_per * units, "kernel": kname,
                          "kernel_ms": ms, "alg_bytes_per_env_step": b_per, "env_steps_per_launch": units,
-                         "note": "at 65 536 envs the fused kernel holds one wave per SIMD and is bound by VALU issue "
-                                 "(~270 instructions per env step and wave, DESIGN.md section 7), not by HBM"},
+                         "note": "at 65 536 envs there is one wave of envs per SIMD: the fused kernel is bound by VALU issue "
+                                 "(~250 instructions per 64 envs and step; k_rollout_ws splits them over two waves per "
+                                 "SIMD, DESIGN.md sections 4 and 7), not by HBM; with records on the write stream "
+                                 "saturates at ~4 TB/s (1.2e11 env-steps/s) from 131 072 envs"},
             "episodes": {"completed": ep["episodes"], "mean_return": ep["mean_return"], "mean_length": ep["mean_length"]},
             "nan_flags": errs,
         }

@@ -232,6 +232,13 @@ int vs_step_random(vs_handle h, uint64_t seed, int k_steps, int record);
  * steps it has taken.  vs_seek_random repositions that counter (0 = start of a fresh batch of rollouts). */
 int vs_seek_random(vs_handle h, uint64_t step_index);
 int vs_set_traj_capacity(vs_handle h, int t_max);
+/* which kernel the next vs_step_random launches for this handle's configuration: 0 = k_rollout (one wave per 64 envs),
+ * 1 = k_rollout_ws (a physics wave and a reward/record wave per 64 envs; chosen while the plain kernel would leave the
+ * SIMDs with a single wave).  Results are bit-identical. */
+int vs_rollout_variant(vs_handle h);
+/* pin the choice: -1 automatic (default), 0 k_rollout, 1 k_rollout_ws where the configuration allows it (no live
+ * randomizer / parameter buffer / wrapper pipeline, no state-and-time dependent final reward), else k_rollout */
+int vs_set_rollout_variant(vs_handle h, int variant);
 /* first row of the VS_TRAJ_* buffers written by the next recording vs_step_random (default 0): consecutive launches can
  * fill one long trajectory buffer, t0 + k_steps <= capacity */
 int vs_set_traj_offset(vs_handle h, int t0);

@@ -57,6 +57,8 @@ _SIGNATURES = {
     "vs_step_jac": (C.c_int, [_P, _P, C.c_int64, C.c_int64]),
     "vs_step_random": (C.c_int, [_P, C.c_uint64, C.c_int, C.c_int]),
     "vs_seek_random": (C.c_int, [_P, C.c_uint64]),
+    "vs_rollout_variant": (C.c_int, [_P]),
+    "vs_set_rollout_variant": (C.c_int, [_P, C.c_int]),
     "vs_set_traj_capacity": (C.c_int, [_P, C.c_int]),
     "vs_set_traj_offset": (C.c_int, [_P, C.c_int]),
     "vs_set_episode_log": (C.c_int, [_P, C.c_int]),

@@ -514,26 +514,45 @@ __global__ __launch_bounds__(BLOCK) void k_step_jac(Task T, Dev d, const float* 
 // a lane writes its w floats with ONE dwordx4 / dwordx2 / dword store and a wave writes 64 * 4 * w contiguous bytes.
 // QQube: 8 floats = 2 stores instead of 8 (and one address computation instead of eight); no padding for any family.
 // Row t of the buffer starts at float offset t * F * ld; plane q at  4 * ld * q  (then the 2-wide, then the 1-wide plane).
+template <int F>
+struct Planes {
+    static constexpr int NQ = F / 4, H2 = (F % 4) >= 2 ? 1 : 0, H1 = F % 2;
+    // v[0 .. F) of env i into a row of planes with `ld` envs per plane (global memory or LDS)
+    __device__ __forceinline__ static void store(float* __restrict__ row, size_t ld, int i, const float* v) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+            reinterpret_cast<float4*>(row + (size_t)q * 4 * ld)[i] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+        if (H2) reinterpret_cast<float2*>(row + (size_t)NQ * 4 * ld)[i] = make_float2(v[4 * NQ], v[4 * NQ + 1]);
+        if (H1) row[((size_t)NQ * 4 + H2 * 2) * ld + i] = v[F - 1];
+    }
+    __device__ __forceinline__ static void load(const float* row, size_t ld, int i, float* v) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            float4 x = reinterpret_cast<const float4*>(row + (size_t)q * 4 * ld)[i];
+            v[4 * q] = x.x, v[4 * q + 1] = x.y, v[4 * q + 2] = x.z, v[4 * q + 3] = x.w;
+        }
+        if (H2) {
+            float2 x = reinterpret_cast<const float2*>(row + (size_t)NQ * 4 * ld)[i];
+            v[4 * NQ] = x.x, v[4 * NQ + 1] = x.y;
+        }
+        if (H1) v[F - 1] = row[((size_t)NQ * 4 + H2 * 2) * ld + i];
+    }
+};
 template <class E>
 struct Rec {
     static constexpr int F = E::O + E::A + 1;
-    static constexpr int NQ = F / 4, H2 = (F % 4) >= 2 ? 1 : 0, H1 = F % 2;
 };
 template <class E>
 __device__ __forceinline__ void store_record(float* __restrict__ row, size_t ld, int i, const float* ob, const float* a,
                                              float rew) {
-    using R = Rec<E>;
-    float v[R::F];
+    constexpr int F = Rec<E>::F;
+    float v[F];
 #pragma unroll
     for (int j = 0; j < E::O; ++j) v[j] = ob[j];
 #pragma unroll
     for (int j = 0; j < E::A; ++j) v[E::O + j] = a[j];
-    v[R::F - 1] = rew;
-#pragma unroll
-    for (int q = 0; q < R::NQ; ++q)
-        reinterpret_cast<float4*>(row + (size_t)q * 4 * ld)[i] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
-    if (R::H2) reinterpret_cast<float2*>(row + (size_t)R::NQ * 4 * ld)[i] = make_float2(v[4 * R::NQ], v[4 * R::NQ + 1]);
-    if (R::H1) row[((size_t)R::NQ * 4 + R::H2 * 2) * ld + i] = v[R::F - 1];
+    v[F - 1] = rew;
+    Planes<F>::store(row, ld, i, v);
 }
 
 // ---------------------------------------------------------------------------------------------------- rollout kernel
@@ -658,6 +677,243 @@ template <class E, bool UNI, bool AR, bool REC, bool PIPE>
 __global__ __launch_bounds__(BLOCK) void k_rollout(Task T, Dev d, int k_steps, uint64_t seed, uint64_t reset_seed,
                                                    uint64_t epoch0) {
     rollout_body<E, UNI, AR, REC, PIPE>(T, d, k_steps, seed, reset_seed, epoch0, (int)blockIdx.x);
+}
+
+// ------------------------------------------------------------------------------------ wave-specialised rollout kernel
+// At the size of the headline metric (65 536 envs) k_rollout has exactly one wave per SIMD, and a lone wave issues a VALU
+// instruction only every ~7 cycles while the SIMD takes one every 4 from two or more waves (the same
+// kernel does 2x the envs in 1.2x the time).  This variant gives every SIMD TWO waves without needing more envs: the step
+// of 64 envs is split between a
+//   P wave ("physics"): ActNorm -> clip -> dead zone -> integrate -> bounds / done -> auto-reset, observe() of the new state
+//                       (owns state, hidden state, step counter)
+//   C wave ("critic"):  the policy's action (Philox), reward of (s_t, a_t), final reward, returns / episode statistics,
+//                       the record stores
+// They exchange through LDS in batches of WS_R env steps, double buffered in both directions: in phase b the P wave
+// integrates batch b with the actions C drew in phase b - 1 and leaves (s_t, obs_t, flags_t) per step; C meanwhile works
+// off the messages of batch b - 1 and draws the actions of batch b + 1.  ONE workgroup barrier per phase (LDS-only wait: the
+// C wave never drains its record stores).  A workgroup is 512 threads = 4 P waves + 4 C waves for 256 envs: the hardware
+// places wave w and wave w + 4 of a workgroup on the same SIMD (scratch/ubench/wave_place.hip: 256 of 256 workgroups), so
+// every SIMD holds one P and one C wave with about half of the instruction stream each.
+// The arithmetic is statement for statement that of step_one / rollout_body (bit-identical results, tested against k_step).
+// Not covered here (vs_step_random falls back to k_rollout): live domain randomisation (constants change inside the launch),
+// the wrapper pipeline, the state-and-time dependent final reward (needs s_{t+1} on the C side).
+constexpr int WS_BLOCK = 512, WS_ENVS = 256;
+enum : unsigned { WSF_DONE = 1u, WSF_FAILED = 2u, WSF_FROZEN = 4u, WSF_FIN = 8u };
+
+__device__ __forceinline__ void ws_barrier() {
+    // LDS traffic only: wait for this wave's LDS ops (lgkmcnt(0)), not for its global stores (a __syncthreads() would also
+    // drain vmcnt and stall the C wave on its record stores in every phase)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+template <class E, bool UNI, bool AR, bool REC, int WS_R>
+__global__ __launch_bounds__(WS_BLOCK) void k_rollout_ws(Task T, Dev d, int k_steps, uint64_t seed, uint64_t reset_seed,
+                                                         uint64_t epoch0) {
+    static_assert(E::FINAL != FINAL_STATE_TIME, "needs the post-step state on the reward side");
+    constexpr int M = E::S + (REC ? E::O : 0) + 1;  // message of one step: s_t | obs_t (records only) | flags
+    __shared__ __attribute__((aligned(16))) float l_msg[2][WS_R][M * WS_ENVS];
+    __shared__ __attribute__((aligned(16))) float l_act[2][WS_R][E::A * WS_ENVS];
+    const int wave = threadIdx.x >> 6;
+    const bool role_c = wave >= WS_BLOCK / 128;
+    const int le = threadIdx.x & (WS_ENVS - 1);  // env slot inside the workgroup
+    const int i = blockIdx.x * WS_ENVS + le;
+    const size_t ld = d.ld;
+    const bool valid = i < d.n;
+    const int nb = (k_steps + WS_R - 1) / WS_R;
+    float c[E::K];
+    load_consts<E, UNI>(d, i, c, 0, E::KS);
+    float alo[E::A], ahi[E::A];
+    E::act_bounds(c, alo, ahi);
+
+    if (!role_c) {
+        // ------------------------------------------------------------------------------------------- P wave
+        float s[E::S], h[E::H > 0 ? E::H : 1], ob[E::O];
+#pragma unroll
+        for (int j = 0; j < E::S; ++j) s[j] = d.state[j * ld + i];
+#pragma unroll
+        for (int j = 0; j < E::H; ++j) h[j] = d.hidden[j * ld + i];
+        int step = d.step[i];
+        uint32_t epi = d.ep_idx[i];
+        bool frozen = !AR && d.done[i] != 0;
+        bool done = d.done[i] != 0, failed = d.failed[i] != 0;
+        if (REC) E::observe(s, ob);
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        ws_barrier();  // the actions of batch 0 are in l_act[0]
+        for (int b = 0; b < nb; ++b) {
+            const int nr = min(WS_R, k_steps - b * WS_R);
+            for (int r = 0; r < nr; ++r) {
+                float a[E::A];
+                Planes<E::A>::load(l_act[b & 1][r], WS_ENVS, le, a);
+                float v[M];
+#pragma unroll
+                for (int j = 0; j < E::S; ++j) v[j] = s[j];
+                if (REC) {
+#pragma unroll
+                    for (int j = 0; j < E::O; ++j) v[E::S + j] = ob[j];
+                }
+                bool fin = false;
+                if (!frozen) {
+                    // the P half of step_one: ActNorm -> limit_act -> _step_dynamics -> curr_step += 1 -> is_done
+                    float an[E::A], ac[E::A];
+                    {
+                        const bool nrm = (T.flags & VS_FLAG_ACT_NORM) != 0;
+                        float lb[E::A], ub[E::A];
+                        E::act_bounds(c, lb, ub);
+#pragma unroll
+                        for (int j = 0; j < E::A; ++j) {
+                            float m = lb[j] + (a[j] + 1.0f) * (ub[j] - lb[j]) * 0.5f;
+                            an[j] = vsel(nrm, m, a[j]);
+                        }
+                    }
+                    bool err = false;
+#pragma unroll
+                    for (int j = 0; j < E::A; ++j) err |= visnan(an[j]);
+                    E::limit_act(c, alo, ahi, an, ac);
+                    E::dynamics(T, c, s, h, ac, REC ? (const float*)ob : (const float*)nullptr);
+                    step += 1;
+                    float slo[E::S], shi[E::S];
+                    E::state_bounds(c, slo, shi);
+                    failed = false;
+#pragma unroll
+                    for (int j = 0; j < E::S; ++j) {
+                        float sv = s[j];
+                        err |= isnan(sv);
+                        failed |= E::SYMMETRIC_BOX ? (fabsf(sv) > shi[j]) : ((sv < slo[j]) | (sv > shi[j]));
+                    }
+                    done = failed | (step >= T.max_steps);
+                    if (err && valid) d.err[i] = 1;
+                    fin = done && valid;
+                }
+                unsigned fl = (done ? WSF_DONE : 0u) | (failed ? WSF_FAILED : 0u) | (frozen ? WSF_FROZEN : 0u) |
+                              (fin ? WSF_FIN : 0u);
+                v[M - 1] = __uint_as_float(fl);
+                Planes<M>::store(l_msg[b & 1][r], WS_ENVS, le, v);
+                if (AR) {
+                    if (__ballot(fin) != 0ull) {
+                        if (fin) {
+                            load_consts<E, UNI>(d, i, c, E::KS, E::K);
+                            reset_lane_sampled<E>(T, d, false, i, reset_seed, (uint64_t)epi, c, s, h);
+                            epi += 1u;
+                            step = 0;
+                        }
+                    }
+                } else {
+                    frozen |= done;
+                }
+                if (REC) E::observe(s, ob);
+            }
+            ws_barrier();
+        }
+        if (!REC) E::observe(s, ob);
+#pragma unroll
+        for (int j = 0; j < E::S; ++j) d.state[j * ld + i] = s[j];
+#pragma unroll
+        for (int j = 0; j < E::H; ++j) d.hidden[j * ld + i] = h[j];
+#pragma unroll
+        for (int j = 0; j < E::O; ++j) d.obs[j * ld + i] = ob[j];
+        d.step[i] = step;
+        d.ep_idx[i] = epi;
+        d.done[i] = done;
+        d.failed[i] = failed;
+    } else {
+        // ------------------------------------------------------------------------------------------- C wave
+        const size_t rec0 = (size_t)d.traj_t0;
+        float ret = d.ret[i];
+        float rew = d.rew[i];
+        bool yielded = E::FINAL != FINAL_NONE ? d.yielded[i] != 0 : false;
+        EpStat es{0u, d.es_count[i], d.es_retsum[i], d.es_lensum[i]};
+        int len = d.step[i];
+        constexpr unsigned SPB = 4 / E::A;
+        uint4 blk = make_uint4(0, 0, 0, 0);
+        // the actions of batch bb: act_space.sample_uniform() per step, the very stream of k_rollout
+        auto draw = [&](int bb) {
+            const int nr = min(WS_R, k_steps - bb * WS_R);
+            for (int r = 0; r < nr; ++r) {
+                const int t = bb * WS_R + r;
+                uint64_t ta = epoch0 + (uint64_t)t;
+                unsigned sub = (unsigned)(ta % SPB);
+                if (t == 0 || sub == 0) blk = Rng::philox(seed, d.idx0 + (uint32_t)i, RNG_ACT, ta / SPB);
+                float a[E::A];
+#pragma unroll
+                for (int j = 0; j < E::A; ++j) {
+                    unsigned e = sub * E::A + j;
+                    uint32_t bits = e == 0 ? blk.x : e == 1 ? blk.y : e == 2 ? blk.z : blk.w;
+                    bool nrm = (T.flags & VS_FLAG_ACT_NORM) != 0;
+                    a[j] = E::sample_action(c, nrm ? -1.0f : alo[j], nrm ? 1.0f : ahi[j], Rng::to_u01(bits), j);
+                }
+                Planes<E::A>::store(l_act[bb & 1][r], WS_ENVS, le, a);
+            }
+        };
+        // reward, returns and records of the steps of batch bb
+        auto work_off = [&](int bb) {
+            const int nr = min(WS_R, k_steps - bb * WS_R);
+            for (int r = 0; r < nr; ++r) {
+                const int t = bb * WS_R + r;
+                float v[M], a[E::A];
+                Planes<M>::load(l_msg[bb & 1][r], WS_ENVS, le, v);
+                Planes<E::A>::load(l_act[bb & 1][r], WS_ENVS, le, a);
+                const unsigned fl = __float_as_uint(v[M - 1]);
+                const bool was_frozen = (fl & WSF_FROZEN) != 0u, fin = (fl & WSF_FIN) != 0u;
+                const bool done = (fl & WSF_DONE) != 0u, failed = (fl & WSF_FAILED) != 0u;
+                if (!was_frozen) {
+                    len += 1;  // curr_step of the running episode, counted on this side too
+                    float an[E::A];
+                    {
+                        const bool nrm = (T.flags & VS_FLAG_ACT_NORM) != 0;
+                        float lb[E::A], ub[E::A];
+                        E::act_bounds(c, lb, ub);
+#pragma unroll
+                        for (int j = 0; j < E::A; ++j) {
+                            float m = lb[j] + (a[j] + 1.0f) * (ub[j] - lb[j]) * 0.5f;
+                            an[j] = vsel(nrm, m, a[j]);
+                        }
+                    }
+                    rew = step_reward<E, float>(T, c, v, an);  // pre-step state, unclipped action (Q3)
+                    if (E::FINAL == FINAL_CONST_MALUS) {  // once per episode (final_reward.py:130-135, 165-174)
+                        if (done && !yielded) {
+                            if (failed) rew += -1000.0f;
+                            yielded = true;
+                        }
+                    }
+                    ret += rew;
+                } else {
+                    rew = 0.f;
+                }
+                if (REC) {
+                    store_record<E>(d.traj_rec + (rec0 + (size_t)t) * Rec<E>::F * ld, ld, i, v + E::S, a, rew);
+                    d.traj_done[(rec0 + (size_t)t) * ld + i] = done;
+                }
+                if (__ballot(fin) != 0ull) {
+                    if (d.log_episodes) append_episode(d, fin, i, ret, len);
+                    if (fin) {
+                        es.count += 1u;
+                        es.retsum += ret;
+                        es.lensum += len;
+                        if (AR) {
+                            ret = 0.f;
+                            yielded = false;
+                            len = 0;
+                        }
+                    }
+                }
+            }
+        };
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        draw(0);
+        ws_barrier();
+        for (int b = 0; b < nb; ++b) {
+            if (b >= 1) work_off(b - 1);  // reads l_act[(b - 1) & 1] before draw(b + 1) overwrites the same buffer
+            if (b + 1 < nb) draw(b + 1);
+            ws_barrier();
+        }
+        work_off(nb - 1);
+        d.ret[i] = ret;
+        d.rew[i] = rew;
+        if (E::FINAL != FINAL_NONE) d.yielded[i] = yielded;
+        d.es_count[i] = es.count;
+        d.es_retsum[i] = es.retsum;
+        d.es_lensum[i] = es.lensum;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------- mixed batches
@@ -904,6 +1160,7 @@ struct vs_env {
     DrSpecs* d_specs = nullptr;   // device scratch for vs_sample_params
     float* d_pbuf = nullptr;      // DomainRandWrapperBuffer parameter sets
     float* d_ring = nullptr;      // ActDelayWrapper ring (Pipe::ring)
+    int rollout_variant = -1;     // vs_set_rollout_variant: -1 automatic, 0 k_rollout, 1 k_rollout_ws
     bool auto_reset = false;
     uint64_t ar_seed = 0;
     bool uniform = true;
@@ -1034,9 +1291,42 @@ static void launch_step(vs_handle h, const float* act, long es, long ds) {
 #undef LS
 }
 
+// The wave-specialised kernel pays while k_rollout would leave a SIMD with a single wave (about 64 lanes x 1024 SIMDs),
+// for the families whose step splits into two comparable halves (E::WS_PAYS), and needs constants that do not change
+// inside the launch.  VS_ROLLOUT_VARIANT=plain|ws and VS_WS_R=1|2|4 override (experiments).
+template <class E>
+static bool use_ws(vs_handle h) {
+    if (E::FINAL == FINAL_STATE_TIME) return false;
+    if (h->dr.n > 0 || h->d.pbuf_n > 0 || h->d.pipe.act_on || h->d.pipe.obs_on) return false;
+    if (h->rollout_variant >= 0) return h->rollout_variant == 1;
+    static const char* force = getenv("VS_ROLLOUT_VARIANT");
+    if (force && force[0] == 'p') return false;
+    if (force && force[0] == 'w') return true;
+    return E::WS_PAYS && h->d.ld <= 81920;  // at 131 072 lanes k_rollout already has two waves per SIMD and wins (87.9 vs 97.4 us)
+}
+
 template <class E>
 static void launch_rollout(vs_handle h, int k, uint64_t seed, uint64_t ep, bool rec) {
     bool uni = h->uniform && h->dr.n == 0;
+    if constexpr (E::FINAL != FINAL_STATE_TIME) {
+        if (use_ws<E>(h)) {
+            dim3 g((unsigned)(h->d.ld / WS_ENVS)), b(WS_BLOCK);
+            static const char* rs = getenv("VS_WS_R");
+            const int wsr = rs ? atoi(rs) : 4;
+#define LW(U, AR, R) do { if (wsr == 1) hipLaunchKernelGGL((k_rollout_ws<E, U, AR, R, 1>), g, b, 0, h->stream, h->task, h->d, k, seed, h->ar_seed, ep); \
+                          else if (wsr == 2) hipLaunchKernelGGL((k_rollout_ws<E, U, AR, R, 2>), g, b, 0, h->stream, h->task, h->d, k, seed, h->ar_seed, ep); \
+                          else hipLaunchKernelGGL((k_rollout_ws<E, U, AR, R, 4>), g, b, 0, h->stream, h->task, h->d, k, seed, h->ar_seed, ep); } while (0)
+            if (uni) {
+                if (h->auto_reset) { if (rec) LW(true, true, true); else LW(true, true, false); }
+                else { if (rec) LW(true, false, true); else LW(true, false, false); }
+            } else {
+                if (h->auto_reset) { if (rec) LW(false, true, true); else LW(false, true, false); }
+                else { if (rec) LW(false, false, true); else LW(false, false, false); }
+            }
+#undef LW
+            return;
+        }
+    }
     dim3 g = grid_for(h->d.ld), b(BLOCK);
 #define LR(U, AR, R) hipLaunchKernelGGL((k_rollout<E, U, AR, R, false>), g, b, 0, h->stream, h->task, h->d, k, seed, h->ar_seed, ep)
 #define LP(AR, R) hipLaunchKernelGGL((k_rollout<E, false, AR, R, true>), g, b, 0, h->stream, h->task, h->d, k, seed, h->ar_seed, ep)
@@ -1496,6 +1786,19 @@ int vs_set_traj_capacity(vs_handle h, int t_max) {
     if ((rc = dalloc(h, &d.traj_done, (size_t)t_max * ld))) return rc;
     h->traj_cap = t_max;
     return VS_OK;
+}
+
+int vs_set_rollout_variant(vs_handle h, int variant) {
+    if (!h || variant < -1 || variant > 1) return fail(h, VS_ERR_ARG, "vs_set_rollout_variant: -1 (automatic), 0 or 1");
+    h->rollout_variant = variant;
+    return VS_OK;
+}
+
+int vs_rollout_variant(vs_handle h) {
+    if (!h) return VS_ERR_ARG;
+    int ws = 0;
+    DISPATCH_ENV(h->type, ws = use_ws<E>(h) ? 1 : 0);
+    return ws;
 }
 
 int vs_set_traj_offset(vs_handle h, int t0) {

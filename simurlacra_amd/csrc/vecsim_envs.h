@@ -196,6 +196,8 @@ template <int A_>
 struct EnvDefaults {
     static constexpr bool SYMMETRIC_BOX = true;  // state box lo == -hi
     static constexpr int FINAL = FINAL_NONE;
+    // the wave-specialised rollout kernel (vecsim.hip, k_rollout_ws) pays for this family at <= 1 wave per SIMD
+    static constexpr bool WS_PAYS = true;
     // Env.limit_act -> BoxSpace.project_to (P/spaces/box.py:180-184); np.clip propagates NaN (fminf/fmaxf would drop it)
     template <class R>
     __device__ static void limit_act(const float*, const float* lo, const float* hi, const R* a_raw, R* a) {
@@ -215,6 +217,7 @@ struct Omo : EnvDefaults<1> {
     static constexpr int S = 2, A = 1, O = 2, H = 0, I = 2, P = 3, K = 4, KS = 4;
     static constexpr int REW = REW_QUADR, RADIAL = -1, CMAX = -1;
     static constexpr int FINAL = FINAL_CONST_MALUS;  // FinalRewTask(factor 1e3, always_negative), :75-79
+    static constexpr bool WS_PAYS = false;  // too little work per step to split (measured: 12 % slower)
     enum { C_A10, C_A11, C_B1, C_AMAX };
     __device__ static void calc_consts(const Task&, const float* p, float* c) {  // _calc_constants :88-103
         float m = p[0], k = p[1], d = p[2];
@@ -614,6 +617,7 @@ __device__ inline float qbb_ik(float th, float r, float l) {
 struct Qbb : EnvDefaults<2> {
     static constexpr int S = 8, A = 2, O = 8, H = 2, I = 4, P = 20, K = 19, KS = 17;
     static constexpr int REW = REW_SCALED_EXP, RADIAL = -1;
+    static constexpr bool WS_PAYS = false;  // 17-float messages and a physics side 3x the reward side (measured: 14-22 % slower)
     enum { C_AM, C_BEQV, C_JEQ, C_CKIN, C_OFFX, C_OFFY, C_TXP, C_TXN, C_TYP, C_TYN, C_BDR2, C_JBR, C_MR2, C_CKMGR2,
            C_ZETA, C_XMAX, C_CMAX, C_IK_X0, C_IK_Y0 };
     static constexpr int CMAX = C_CMAX;

@@ -376,6 +376,15 @@ class VecSimEnv:
         self._check(self._lib.vs_set_traj_offset(self._h, int(t0)), "vs_set_traj_offset")
         self._traj_t0 = int(t0)
 
+    def set_rollout_variant(self, variant=None):
+        """None: automatic; 'k_rollout' / 'k_rollout_ws' pin the fused kernel (bit-identical results either way)"""
+        code = {None: -1, "k_rollout": 0, "k_rollout_ws": 1}[variant]
+        self._check(self._lib.vs_set_rollout_variant(self._h, code), "vs_set_rollout_variant")
+
+    def rollout_variant(self):
+        """'k_rollout' or 'k_rollout_ws': the kernel vs_step_random launches for the current configuration"""
+        return "k_rollout_ws" if self._lib.vs_rollout_variant(self._h) == 1 else "k_rollout"
+
     def traj_layout(self):
         """(F, nq, h2, h1): a record is F = O + A + 1 floats [obs | act | rew], stored as nq planes of 4, h2 of 2 and h1 of 1
         floats per env (include/vecsim.h, VS_TRAJ_REC)"""

@@ -858,3 +858,76 @@ def test_bernoulli_rounded_and_1d_multivariate_params_on_device(vs):
         env.sample_params([("mass", "poisson", 1.0, 2.0, -np.inf, np.inf)])
     env.close()
     env2.close()
+
+
+@pytest.mark.parametrize("auto_reset", [False, True])
+@pytest.mark.parametrize("name", ["qq-su", "qcp-su", "bob", "omo", "qbb", "pend", "bob-d", "qq-st"])
+def test_wave_specialised_rollout_kernel_equals_plain_kernel(vs, name, auto_reset):
+    """k_rollout_ws (a physics wave + a reward/record wave per 64 envs, exchanging through LDS) against k_rollout: records,
+    final buffers, episode statistics and the episode log bit for bit; launches of 7, 1 and 30 steps (batches of 4 with a
+    ragged tail), per-env and broadcast constants, n not a multiple of the 256-env workgroup"""
+    L = vs._lib
+    n = 1000
+    kw = dict(KW[name])
+    kw["max_steps"] = 25  # time-outs inside the window
+    for per_env in (False, True):
+        pair = []
+        for variant in ("k_rollout", "k_rollout_ws"):
+            e = vs.VecSimEnv(name, n, **kw)
+            if per_env:
+                e.set_params(np.tile(vs.nominal_params(name), (n, 1)))
+            e.set_rollout_variant(variant)
+            assert e.rollout_variant() == variant
+            e.set_auto_reset(auto_reset, seed=17)
+            e.set_episode_log(True)
+            e.reset(seed=1)
+            e.set_traj_capacity(38)
+            t = 0
+            for k in (7, 1, 30):
+                e.set_traj_offset(t)
+                e.step_random(k, seed=4, record=True)
+                t += k
+            e.set_traj_offset(0)
+            e.step_random(5, seed=9, record=False)  # the variant without records (no observation in the message)
+            pair.append(e)
+        a, b = pair
+        ta, tb = a.traj(38), b.traj(38)
+        for key in ("obs", "act", "rew", "done"):
+            assert np.array_equal(ta[key], tb[key]), (name, key)
+        assert ta["done"].any()
+        for which in (L.VS_STATE, L.VS_OBS, L.VS_HIDDEN, L.VS_STEPCOUNT, L.VS_RETURNS, L.VS_REW, L.VS_DONE, L.VS_FAILED):
+            assert np.array_equal(a.get(which), b.get(which)), (name, which)
+        for x, y in zip(a.episode_stats(), b.episode_stats()):
+            assert np.array_equal(x, y)
+        ra, la, ia = a.episodes()
+        rb, lb, ib = b.episodes()
+        assert sorted(zip(ia.tolist(), la.tolist(), ra.tolist())) == sorted(zip(ib.tolist(), lb.tolist(), rb.tolist()))
+        assert len(ra) > 0 and a.error_count() == b.error_count() == 0
+        a.close()
+        b.close()
+
+
+def test_rollout_variant_selection(vs):
+    """automatic choice: the wave-specialised kernel below two waves of envs per SIMD, for the families it pays for, and
+    never with live randomisation / a parameter buffer / a wrapper pipeline / the state-and-time dependent final reward"""
+    e = vs.VecSimEnv("qq-su", 65536, **KW["qq-su"])
+    assert e.rollout_variant() == "k_rollout_ws"
+    e.set_randomizer([("gravity_const", "normal", 9.81, 1.0, 1e-4, np.inf)])
+    assert e.rollout_variant() == "k_rollout"
+    e.set_randomizer([])
+    e.set_act_pipeline(delay=1)
+    assert e.rollout_variant() == "k_rollout"
+    e.set_rollout_variant("k_rollout_ws")
+    assert e.rollout_variant() == "k_rollout"  # the pipeline still wins over the pin
+    e.set_act_pipeline(delay=0)
+    assert e.rollout_variant() == "k_rollout_ws"
+    e.close()
+    big = vs.VecSimEnv("qq-su", 131072, **KW["qq-su"])
+    assert big.rollout_variant() == "k_rollout"
+    big.close()
+    for name, expect in (("omo", "k_rollout"), ("qbb", "k_rollout"), ("qcp-st", "k_rollout"), ("bob", "k_rollout_ws")):
+        x = vs.VecSimEnv(name, 4096, **KW[name])
+        assert x.rollout_variant() == expect, name
+        x.set_rollout_variant("k_rollout_ws")
+        assert x.rollout_variant() == ("k_rollout" if name == "qcp-st" else "k_rollout_ws")
+        x.close()
