@@ -12,3 +12,4 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch_step16m -- python3 
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write_step16m -- python3 bench.py --no-cpu-baseline --mode step --envs 16777216 --steps 30 --warmup 5 > /dev/null 2> $OUT/w2.err
 python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 cat $OUT/bench_default.json
+python3 scratch/make_traffic.py $OUT $OUT/traffic.json
