@@ -710,7 +710,8 @@ template <class E, bool UNI, bool AR, bool REC, int WS_R>
 __global__ __launch_bounds__(WS_BLOCK) void k_rollout_ws(Task T, Dev d, int k_steps, uint64_t seed, uint64_t reset_seed,
                                                          uint64_t epoch0) {
     static_assert(E::FINAL != FINAL_STATE_TIME, "needs the post-step state on the reward side");
-    constexpr int M = E::S + (REC ? E::O : 0) + 1;  // message of one step: s_t | obs_t (records only) | flags
+    constexpr int M0 = E::S + (REC ? E::O : 0) + 1;  // message of one step: s_t | obs_t (records only) | flags
+    constexpr int M = M0 % 4 == 3 ? M0 + 1 : M0;     // 4k + 3 floats would be three LDS ops for the tail; pad to a quad
     __shared__ __attribute__((aligned(16))) float l_msg[2][WS_R][M * WS_ENVS];
     __shared__ __attribute__((aligned(16))) float l_act[2][WS_R][E::A * WS_ENVS];
     const int wave = threadIdx.x >> 6;
@@ -751,7 +752,7 @@ __global__ __launch_bounds__(WS_BLOCK) void k_rollout_ws(Task T, Dev d, int k_st
 #pragma unroll
                     for (int j = 0; j < E::O; ++j) v[E::S + j] = ob[j];
                 }
-                bool fin = false;
+                bool fin = false;  // (used for the reset on this side)
                 if (!frozen) {
                     // the P half of step_one: ActNorm -> limit_act -> _step_dynamics -> curr_step += 1 -> is_done
                     float an[E::A], ac[E::A];
@@ -784,9 +785,10 @@ __global__ __launch_bounds__(WS_BLOCK) void k_rollout_ws(Task T, Dev d, int k_st
                     if (err && valid) d.err[i] = 1;
                     fin = done && valid;
                 }
-                unsigned fl = (done ? WSF_DONE : 0u) | (failed ? WSF_FAILED : 0u) | (frozen ? WSF_FROZEN : 0u) |
-                              (fin ? WSF_FIN : 0u);
-                v[M - 1] = __uint_as_float(fl);
+                unsigned fl = (done ? WSF_DONE : 0u) | (E::FINAL != FINAL_NONE && failed ? WSF_FAILED : 0u) |
+                              (!AR && frozen ? WSF_FROZEN : 0u);  // fin = done & !frozen & valid is recomputed by C
+                v[M0 - 1] = __uint_as_float(fl);
+                if (M > M0) v[M - 1] = 0.f;
                 Planes<M>::store(l_msg[b & 1][r], WS_ENVS, le, v);
                 if (AR) {
                     if (__ballot(fin) != 0ull) {
@@ -852,9 +854,10 @@ __global__ __launch_bounds__(WS_BLOCK) void k_rollout_ws(Task T, Dev d, int k_st
                 float v[M], a[E::A];
                 Planes<M>::load(l_msg[bb & 1][r], WS_ENVS, le, v);
                 Planes<E::A>::load(l_act[bb & 1][r], WS_ENVS, le, a);
-                const unsigned fl = __float_as_uint(v[M - 1]);
-                const bool was_frozen = (fl & WSF_FROZEN) != 0u, fin = (fl & WSF_FIN) != 0u;
+                const unsigned fl = __float_as_uint(v[M0 - 1]);
+                const bool was_frozen = !AR ? (fl & WSF_FROZEN) != 0u : false;
                 const bool done = (fl & WSF_DONE) != 0u, failed = (fl & WSF_FAILED) != 0u;
+                const bool fin = done && !was_frozen && valid;
                 if (!was_frozen) {
                     len += 1;  // curr_step of the running episode, counted on this side too
                     float an[E::A];
@@ -1293,7 +1296,7 @@ static void launch_step(vs_handle h, const float* act, long es, long ds) {
 
 // The wave-specialised kernel pays while k_rollout would leave a SIMD with a single wave (about 64 lanes x 1024 SIMDs),
 // for the families whose step splits into two comparable halves (E::WS_PAYS), and needs constants that do not change
-// inside the launch.  VS_ROLLOUT_VARIANT=plain|ws and VS_WS_R=1|2|4 override (experiments).
+// inside the launch.  VS_ROLLOUT_VARIANT=plain|ws overrides for every handle (experiments).
 template <class E>
 static bool use_ws(vs_handle h) {
     if (E::FINAL == FINAL_STATE_TIME) return false;
@@ -1311,11 +1314,8 @@ static void launch_rollout(vs_handle h, int k, uint64_t seed, uint64_t ep, bool 
     if constexpr (E::FINAL != FINAL_STATE_TIME) {
         if (use_ws<E>(h)) {
             dim3 g((unsigned)(h->d.ld / WS_ENVS)), b(WS_BLOCK);
-            static const char* rs = getenv("VS_WS_R");
-            const int wsr = rs ? atoi(rs) : 4;
-#define LW(U, AR, R) do { if (wsr == 1) hipLaunchKernelGGL((k_rollout_ws<E, U, AR, R, 1>), g, b, 0, h->stream, h->task, h->d, k, seed, h->ar_seed, ep); \
-                          else if (wsr == 2) hipLaunchKernelGGL((k_rollout_ws<E, U, AR, R, 2>), g, b, 0, h->stream, h->task, h->d, k, seed, h->ar_seed, ep); \
-                          else hipLaunchKernelGGL((k_rollout_ws<E, U, AR, R, 4>), g, b, 0, h->stream, h->task, h->d, k, seed, h->ar_seed, ep); } while (0)
+            // R = 4 steps per exchange (measured on the headline config: R = 1 / 2 / 4 -> 68.7 / 64.8 / 62.0 us per 100 steps)
+#define LW(U, AR, R) hipLaunchKernelGGL((k_rollout_ws<E, U, AR, R, 4>), g, b, 0, h->stream, h->task, h->d, k, seed, h->ar_seed, ep)
             if (uni) {
                 if (h->auto_reset) { if (rec) LW(true, true, true); else LW(true, true, false); }
                 else { if (rec) LW(true, false, true); else LW(true, false, false); }
