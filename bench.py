@@ -261,6 +261,17 @@ def main():
             units = n
             kname = "k_step"
         achieved = b_per * units / (ms * 1e-3) / 1e9
+        # the practical HBM ceiling next to the nominal one -- an in-repo float4 copy kernel (read + write of
+        # 1 GiB per pass, far beyond the caches), timed with HIP events
+        copy_gbs = None
+        try:
+            import ctypes
+
+            g = ctypes.c_float()
+            if L.load().vs_membw_probe(local_rank, 1 << 30, 10, ctypes.byref(g)) == 0:
+                copy_gbs = float(g.value)
+        except Exception:
+            pass
         # HBM bytes per launch from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 passes of this very
         # command; gfx950 correction applied) -- measured once per round and committed under profiles/
         traffic, traffic_src = None, None
@@ -289,13 +300,16 @@ def main():
                        "envs_per_gpu": n, "env": args.env, "mode": args.mode, "chunk": chunk, "record": args.record,
                        "parallelism": f"env-shard x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_unit": "bytes/launch (PMC)",
+                         "frac": achieved / HBM_PEAK_GBS, "copy_kernel_GBs": copy_gbs,
+                         "frac_of_copy_kernel": (achieved / copy_gbs) if copy_gbs else None, "traffic": traffic, "traffic_unit": "bytes/launch (PMC)",
                          "traffic_source": traffic_src, "alg_bytes_per_launch": b_per * units, "kernel": kname,
                          "kernel_ms": ms, "alg_bytes_per_env_step": b_per, "env_steps_per_launch": units,
-                         "note": "at 65 536 envs there is one wave of envs per SIMD: the fused kernel is bound by VALU issue "
-                                 "(~250 instructions per 64 envs and step; k_rollout_ws splits them over two waves per "
-                                 "SIMD, DESIGN.md sections 4 and 7), not by HBM; with records on the write stream "
-                                 "saturates at ~4 TB/s (1.2e11 env-steps/s) from 131 072 envs"},
+                         "note": ("at 65 536 envs there is one wave of envs per SIMD: the fused kernel is bound by VALU issue "
+                                  "(~250 instructions per 64 envs and step; k_rollout_ws splits them over two waves per "
+                                  "SIMD, DESIGN.md sections 4 and 7), not by HBM; with records on the write stream "
+                                  "saturates at ~4 TB/s (1.2e11 env-steps/s) from 131 072 envs") if args.mode == "fused" else
+                                 ("one launch per env step; HBM-bound from ~1 M envs (at the rate of the in-repo copy kernel "
+                                  "at 16.7 M envs), launch-latency-bound at 65 536")},
             "episodes": {"completed": ep["episodes"], "mean_return": ep["mean_return"], "mean_length": ep["mean_length"]},
             "nan_flags": errs,
         }
