@@ -133,6 +133,8 @@ def main():
     ap.add_argument("--chunk", type=int, default=100, help="env steps per launch in fused mode")
     ap.add_argument("--record", type=int, default=1)
     ap.add_argument("--per-env-params", type=int, default=1, help="1: per-env constants [K][N] (DR-capable), 0: broadcast")
+    ap.add_argument("--live-dr", type=int, default=0, help="DomainRandWrapperLive on the device: redraw the first K parameters "
+                    "of the family's default randomizer at every reset (BASELINE config 3: qcp-su with K = 7)")
     ap.add_argument("--graph", type=int, default=0, help="step mode: capture `chunk` policy+step iterations in one hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=0)
@@ -172,6 +174,9 @@ def main():
     env = vs.VecSimEnv(args.env, n, device=local_rank, **kw)
     if args.per_env_params:
         env.set_params(np.tile(vs.nominal_params(args.env), (n, 1)))
+    if args.live_dr:
+        rz = vs.create_default_randomizer(vs.ENV_CLASSES[args.env](**kw))
+        env.set_randomizer(rz.device_specs()[: args.live_dr])
     from simurlacra_amd.dist import gather_episode_stats, shard
 
     first, _ = shard(n * world, rank, world)
@@ -296,7 +301,8 @@ def main():
                                    f"policy on device, auto-reset, mode={args.mode}"
                                    + (f", {chunk} steps/launch, record={args.record}" if args.mode == "fused" else "")
                                    + (f", hipGraph of {chunk} (policy, step) pairs" if graph is not None else "")
-                                   + (", per-env constants" if args.per_env_params else ", broadcast constants"),
+                                   + (", per-env constants" if args.per_env_params else ", broadcast constants")
+                                   + (f", live domain randomisation of {args.live_dr} parameters at every reset" if args.live_dr else ""),
                        "envs_per_gpu": n, "env": args.env, "mode": args.mode, "chunk": chunk, "record": args.record,
                        "parallelism": f"env-shard x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -236,8 +236,9 @@ int vs_set_traj_capacity(vs_handle h, int t_max);
  * 1 = k_rollout_ws (a physics wave and a reward/record wave per 64 envs; chosen while the plain kernel would leave the
  * SIMDs with a single wave).  Results are bit-identical. */
 int vs_rollout_variant(vs_handle h);
-/* pin the choice: -1 automatic (default), 0 k_rollout, 1 k_rollout_ws where the configuration allows it (no live
- * randomizer / parameter buffer / wrapper pipeline, no state-and-time dependent final reward), else k_rollout */
+/* pin the choice: -1 automatic (default), 0 k_rollout, 1 k_rollout_ws where the configuration allows it (no wrapper
+ * pipeline, no state-and-time dependent final reward; a live randomizer / parameter buffer only for the families with
+ * fixed action bounds and an unscaled reward: qq-*, qcp-su), else k_rollout */
 int vs_set_rollout_variant(vs_handle h, int variant);
 /* first row of the VS_TRAJ_* buffers written by the next recording vs_step_random (default 0): consecutive launches can
  * fill one long trajectory buffer, t0 + k_steps <= capacity */

@@ -57,7 +57,9 @@ struct Dev {
     float* es_retsum;
     int* es_lensum;
     int log_episodes;   // opt-in: also append (return, length, env) to the global ring with ballot compaction
-    const DrSpecs* dr;  // device copy of the live randomizer
+    DrSpecs drv;        // the live randomizer BY VALUE: kernel arguments live in the constant address space, so a spec is
+                        // fetched with scalar loads (lgkmcnt).  Behind a pointer it was a vector load per spec, and on
+                        // gfx950 a vector load waits for every older record store (one in-order vmcnt): 1-2 us each
     uint32_t idx0;      // global index of lane 0: every Philox stream is keyed by (idx0 + lane), so results do not depend
                         // on how a set of envs is split into handles, batches or GPUs
     const float* pbuf;  // DomainRandWrapperBuffer: [P][pbuf_n] parameter sets (nullptr: none)
@@ -75,13 +77,7 @@ struct Dev {
 };
 
 // ------------------------------------------------------------------------------------------------- wrapper pipeline
-__device__ __forceinline__ void box_muller(uint32_t b0, uint32_t b1, float& z0, float& z1) {
-    float u1 = 1.0f - Rng::to_u01(b0);  // (0, 1]
-    float r = sqrtf(-2.0f * logf(u1)), sn, cs;
-    sincosf(TWO_PI_F * Rng::to_u01(b1), &sn, &cs);
-    z0 = r * cs;
-    z1 = r * sn;
-}
+__device__ __forceinline__ void box_muller(uint32_t b0, uint32_t b1, float& z0, float& z1) { Rng::box_muller(b0, b1, z0, z1); }
 
 // a: the action in the env's own units (after ActNormWrapper); step: curr_step of the lane before this step
 template <class E>
@@ -297,7 +293,7 @@ __device__ __forceinline__ void redraw_lane_params(const Task& T, const Dev& d, 
 template <class E>
 __device__ __forceinline__ void reset_lane_sampled(const Task& T, const Dev& d, bool with_dr, int i, uint64_t seed,
                                                    uint64_t epi, float* c, float* s, float* h) {
-    if (with_dr && d.dr_n > 0) redraw_lane_params<E>(T, d, d.dr, i, seed, epi, c);
+    if (with_dr && d.dr_n > 0) redraw_lane_params<E>(T, d, &d.drv, i, seed, epi, c);
     if (with_dr && d.pbuf_n > 0) {
         // DomainRandWrapperBuffer.reset (domain_randomization.py:236-251): next set of the ring, or a random one
         uint32_t k;
@@ -695,8 +691,9 @@ __global__ __launch_bounds__(BLOCK) void k_rollout(Task T, Dev d, int k_steps, u
 // places wave w and wave w + 4 of a workgroup on the same SIMD (scratch/ubench/wave_place.hip: 256 of 256 workgroups), so
 // every SIMD holds one P and one C wave with about half of the instruction stream each.
 // The arithmetic is statement for statement that of step_one / rollout_body (bit-identical results, tested against k_step).
-// Not covered here (vs_step_random falls back to k_rollout): live domain randomisation (constants change inside the launch),
-// the wrapper pipeline, the state-and-time dependent final reward (needs s_{t+1} on the C side).
+// Not covered here (vs_step_random falls back to k_rollout): live domain randomisation for the families whose C wave reads
+// per-env constants (action bounds, c_max: they change at a reset inside the launch), the wrapper pipeline, the
+// state-and-time dependent final reward (needs s_{t+1} on the C side).
 constexpr int WS_BLOCK = 512, WS_ENVS = 256;
 enum : unsigned { WSF_DONE = 1u, WSF_FAILED = 2u, WSF_FROZEN = 4u, WSF_FIN = 8u };
 
@@ -794,10 +791,13 @@ __global__ __launch_bounds__(WS_BLOCK) void k_rollout_ws(Task T, Dev d, int k_st
                     if (__ballot(fin) != 0ull) {
                         if (fin) {
                             load_consts<E, UNI>(d, i, c, E::KS, E::K);
-                            reset_lane_sampled<E>(T, d, false, i, reset_seed, (uint64_t)epi, c, s, h);
+                            // live domain randomisation redraws the lane's parameters here: allowed for the families
+                            // whose C wave does not read constants (use_ws)
+                            reset_lane_sampled<E>(T, d, !UNI, i, reset_seed, (uint64_t)epi, c, s, h);
                             epi += 1u;
                             step = 0;
                         }
+                        if (!UNI) E::act_bounds(c, alo, ahi);
                     }
                 } else {
                     frozen |= done;
@@ -1159,7 +1159,6 @@ struct vs_env {
     int device = 0;
     Task task{};
     DrSpecs dr{};                 // host copy of the live randomizer
-    DrSpecs* d_dr = nullptr;      // its device copy (Dev::dr)
     DrSpecs* d_specs = nullptr;   // device scratch for vs_sample_params
     float* d_pbuf = nullptr;      // DomainRandWrapperBuffer parameter sets
     float* d_ring = nullptr;      // ActDelayWrapper ring (Pipe::ring)
@@ -1300,8 +1299,11 @@ static void launch_step(vs_handle h, const float* act, long es, long ds) {
 template <class E>
 static bool use_ws(vs_handle h) {
     if (E::FINAL == FINAL_STATE_TIME) return false;
-    if (h->dr.n > 0 || h->d.pbuf_n > 0 || h->d.pipe.act_on || h->d.pipe.obs_on) return false;
+    if (h->d.pipe.act_on || h->d.pipe.obs_on) return false;
+    const bool live = h->dr.n > 0 || h->d.pbuf_n > 0;
+    if (live && E::REWARD_SIDE_USES_CONSTS) return false;
     if (h->rollout_variant >= 0) return h->rollout_variant == 1;
+    if (live && !E::WS_WITH_LIVE_DR) return false;
     static const char* force = getenv("VS_ROLLOUT_VARIANT");
     if (force && force[0] == 'p') return false;
     if (force && force[0] == 'w') return true;
@@ -1491,9 +1493,7 @@ int vs_create(int env_type, int64_t n_envs, double dt, int64_t max_steps, int de
     CK(dalloc(h, &d.es_count, ld));
     CK(dalloc(h, &d.es_retsum, ld));
     CK(dalloc(h, &d.es_lensum, ld));
-    CK(dalloc(h, &h->d_dr, (size_t)1));
     CK(dalloc(h, &h->d_specs, (size_t)1));
-    d.dr = h->d_dr;
     d.ep_cap = (unsigned)(ld < (1u << 16) ? (1u << 16) : ld);
     CK(dalloc(h, &d.ep_ret, (size_t)d.ep_cap));
     CK(dalloc(h, &d.ep_len, (size_t)d.ep_cap));
@@ -1606,9 +1606,8 @@ int vs_set_randomizer(vs_handle h, const vs_dp_spec* specs, int n_specs) {
     HIPCHK(h, hipSetDevice(h->device));
     if (dr.n > 0 && h->d.pbuf_n > 0) return fail(h, VS_ERR_STATE, "vs_set_randomizer: a parameter buffer is set");
     h->dr = dr;
+    h->d.drv = dr;  // travels with every launch as part of the kernel arguments
     h->d.dr_n = dr.n;
-    HIPCHK(h, hipMemcpyAsync(h->d_dr, &h->dr, sizeof(DrSpecs), hipMemcpyHostToDevice, h->stream));
-    HIPCHK(h, hipStreamSynchronize(h->stream));
     if (n_specs > 0) h->uniform = false;
     return VS_OK;
 }

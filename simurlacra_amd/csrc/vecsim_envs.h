@@ -182,10 +182,22 @@ struct Rng {
     }
     __device__ __forceinline__ float u01() { return to_u01(next()); }  // [0, 1)
     __device__ __forceinline__ float uniform(float lo, float hi) { return lo + (hi - lo) * u01(); }
-    __device__ __forceinline__ float normal() {  // Box-Muller, one value per two uniforms
-        float u1 = 1.0f - u01();                 // (0, 1]
-        float u2 = u01();
-        return sqrtf(-2.0f * logf(u1)) * cosf(TWO_PI_F * u2);
+    // Box-Muller on the hardware transcendentals: v_log_f32 (log2), v_sqrt_f32 and v_cos_f32 / v_sin_f32, whose argument is
+    // in revolutions -- cos(2 pi u) is ONE instruction.  The library logf / cosf / sqrtf are ~350 instructions for the same
+    // draw, executed by a whole wave for the few lanes that reset (live domain randomisation was 2.4x slower with them).
+    // Absolute error of a draw ~1e-6 (3e-4 for |z| < 1e-3, where log(u1) vanishes): statistics, not bits, define these draws.
+    __device__ __forceinline__ static void box_muller(uint32_t b0, uint32_t b1, float& z0, float& z1) {
+        float u1 = 1.0f - to_u01(b0);  // (0, 1]
+        float u2 = to_u01(b1);         // [0, 1) revolutions
+        float r = __builtin_amdgcn_sqrtf(-1.3862944f * __builtin_amdgcn_logf(u1));  // sqrt(-2 ln u1), ln = ln2 * log2
+        z0 = r * __builtin_amdgcn_cosf(u2);
+        z1 = r * __builtin_amdgcn_sinf(u2);
+    }
+    __device__ __forceinline__ float normal() {  // one value per two uniforms
+        uint32_t b0 = next(), b1 = next();
+        float z0, z1;
+        box_muller(b0, b1, z0, z1);
+        return z0;
     }
 };
 enum RngPurpose { RNG_ACT = 1, RNG_INIT = 2, RNG_PARAM = 3, RNG_ACT_NOISE = 4, RNG_OBS_NOISE = 5 };
@@ -198,6 +210,12 @@ struct EnvDefaults {
     static constexpr int FINAL = FINAL_NONE;
     // the wave-specialised rollout kernel (vecsim.hip, k_rollout_ws) pays for this family at <= 1 wave per SIMD
     static constexpr bool WS_PAYS = true;
+    // ... and its reward / record wave reads per-env constants (action bounds, c_max): then the constants must not change
+    // inside a launch, i.e. no live domain randomisation.  False where bounds are fixed numbers and the reward is unscaled.
+    static constexpr bool REWARD_SIDE_USES_CONSTS = true;
+    // ... and whether it still pays with a live randomizer: the redraw runs on the physics wave alone while the other
+    // waits, so only for long episodes (QCartPole swing-up: ~5 000 steps per episode, +8 %; QQube: ~540, -20 %)
+    static constexpr bool WS_WITH_LIVE_DR = false;
     // Env.limit_act -> BoxSpace.project_to (P/spaces/box.py:180-184); np.clip propagates NaN (fminf/fmaxf would drop it)
     template <class R>
     __device__ static void limit_act(const float*, const float* lo, const float* hi, const R* a_raw, R* a) {
@@ -346,6 +364,7 @@ template <int V>
 struct QQT : EnvDefaults<1> {
     static constexpr int S = 4, A = 1, O = 6, H = 0, I = 4, P = 11, K = 11, KS = 11;
     static constexpr int REW = REW_EXP, RADIAL = 1, CMAX = -1;
+    static constexpr bool REWARD_SIDE_USES_CONSTS = false;
     enum { C_C0, C_C1, C_C2, C_C3, C_C4, C_KM, C_RM, C_DR, C_DP, C_TH_NEG, C_TH_POS };
     __device__ static void calc_consts(const Task&, const float* p, float* c) {  // _calc_constants :70-87
         float g = p[0], Rm = p[1], km = p[2], mr = p[3], Lr = p[4], Dr = p[5], mp = p[6], Lp = p[7], Dp = p[8];
@@ -432,6 +451,8 @@ template <int V>
 struct QcpT : EnvDefaults<1> {
     static constexpr int S = 4, A = 1, O = 5, H = 1, I = 4, P = 17, K = 16, KS = 16;
     static constexpr int REW = V == 1 ? REW_QUADR : REW_EXP, RADIAL = 1, CMAX = -1;
+    static constexpr bool REWARD_SIDE_USES_CONSTS = false;
+    static constexpr bool WS_WITH_LIVE_DR = V == 0;
     static constexpr bool SYMMETRIC_BOX = V == 0;
     static constexpr int FINAL = V == 1 ? FINAL_STATE_TIME : FINAL_NONE;
     enum { C_KA, C_ETA_M, C_KB, C_MTG, C_MPL2, C_MU, C_M00, C_MPL, C_M11, C_BEQ, C_BP, C_MPLG, C_TH_NEG, C_TH_POS,

@@ -870,12 +870,18 @@ def test_wave_specialised_rollout_kernel_equals_plain_kernel(vs, name, auto_rese
     n = 1000
     kw = dict(KW[name])
     kw["max_steps"] = 25  # time-outs inside the window
-    for per_env in (False, True):
+    live_dr = {"qq-su": ("mass_pend_pole", 0.024), "qcp-su": ("pole_length", 0.16825), "qq-st": ("length_pend_pole", 0.129)}
+    for per_env in (False, True, "live-dr"):
+        if per_env == "live-dr" and not (auto_reset and name in live_dr):
+            continue
         pair = []
         for variant in ("k_rollout", "k_rollout_ws"):
             e = vs.VecSimEnv(name, n, **kw)
-            if per_env:
+            if per_env is True:
                 e.set_params(np.tile(vs.nominal_params(name), (n, 1)))
+            if per_env == "live-dr":  # parameters redrawn at every auto-reset inside the launches
+                pname, nominal = live_dr[name]
+                e.set_randomizer([(pname, "normal", nominal, nominal / 5, 1e-3, np.inf)])
             e.set_rollout_variant(variant)
             assert e.rollout_variant() == variant
             e.set_auto_reset(auto_reset, seed=17)
@@ -895,8 +901,11 @@ def test_wave_specialised_rollout_kernel_equals_plain_kernel(vs, name, auto_rese
         for key in ("obs", "act", "rew", "done"):
             assert np.array_equal(ta[key], tb[key]), (name, key)
         assert ta["done"].any()
-        for which in (L.VS_STATE, L.VS_OBS, L.VS_HIDDEN, L.VS_STEPCOUNT, L.VS_RETURNS, L.VS_REW, L.VS_DONE, L.VS_FAILED):
+        for which in (L.VS_STATE, L.VS_OBS, L.VS_HIDDEN, L.VS_STEPCOUNT, L.VS_RETURNS, L.VS_REW, L.VS_DONE, L.VS_FAILED,
+                      L.VS_PARAMS, L.VS_CONSTS):
             assert np.array_equal(a.get(which), b.get(which)), (name, which)
+        if per_env == "live-dr":
+            assert len(np.unique(a.get(L.VS_PARAMS)[:, vs.param_names(name).index(live_dr[name][0])])) > n // 2
         for x, y in zip(a.episode_stats(), b.episode_stats()):
             assert np.array_equal(x, y)
         ra, la, ia = a.episodes()
@@ -913,8 +922,19 @@ def test_rollout_variant_selection(vs):
     e = vs.VecSimEnv("qq-su", 65536, **KW["qq-su"])
     assert e.rollout_variant() == "k_rollout_ws"
     e.set_randomizer([("gravity_const", "normal", 9.81, 1.0, 1e-4, np.inf)])
-    assert e.rollout_variant() == "k_rollout"
+    assert e.rollout_variant() == "k_rollout"  # allowed (the C wave needs no constants) but it does not pay: short episodes
+    e.set_rollout_variant("k_rollout_ws")
+    assert e.rollout_variant() == "k_rollout_ws"
+    e.set_rollout_variant(None)
     e.set_randomizer([])
+    q = vs.VecSimEnv("qcp-su", 4096, **KW["qcp-su"])
+    q.set_randomizer([("gravity_const", "normal", 9.81, 1.0, 1e-4, np.inf)])
+    assert q.rollout_variant() == "k_rollout_ws"  # BASELINE config 3: long episodes, the redraw is rare
+    q.close()
+    b = vs.VecSimEnv("bob", 4096, **KW["bob"])
+    b.set_randomizer([("gravity_const", "normal", 9.81, 1.0, 1e-4, np.inf)])
+    assert b.rollout_variant() == "k_rollout"  # act bound and c_max follow the redrawn parameters
+    b.close()
     e.set_act_pipeline(delay=1)
     assert e.rollout_variant() == "k_rollout"
     e.set_rollout_variant("k_rollout_ws")
