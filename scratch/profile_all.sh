@@ -2,7 +2,7 @@
 # rocprofv3 evidence for the default bench command: kernel-trace stats + HBM traffic counters in separate passes
 set -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-OUT=gpurun_out/prof_$1; mkdir -p $OUT
+OUT=gpurun_out/prof_$1; rm -rf $OUT; mkdir -p $OUT
 ARGS="--no-cpu-baseline --steps 30 --warmup 5"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/trace.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 bench.py $ARGS > $OUT/bench_fetch.json 2> $OUT/fetch.err
