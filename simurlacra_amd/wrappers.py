@@ -441,46 +441,48 @@ class GaussianObsNoiseWrapper(EnvWrapperObs):
 
 
 class ObsNormWrapper(EnvWrapperObs):
-    """(obs - lb) / (ub - lb) * 2 - 1 with optional per-label overrides of infinite bounds
-    (P/environment_wrappers/observation_normalization.py:41-126)"""
+    """Maps the observation box to [-1, 1]: (obs - lb) / (ub - lb) * 2 - 1, where infinite bounds of the wrapped space must
+    be replaced through `explicit_lb` / `explicit_ub` ({label: bound}) (P/environment_wrappers/observation_normalization.py:
+    41-126).  Error behaviour as there: an override dict that leaves an infinite entry untouched, or a bound that is still
+    infinite afterwards, raises ValueErr."""
 
     def __init__(self, wrapped_env, explicit_lb=None, explicit_ub=None):
         super().__init__(wrapped_env)
-        self.explicit_lb = explicit_lb
-        self.explicit_ub = explicit_ub
-        wos = self.wrapped_env.obs_space
-        lb, ub = wos.bounds
-        self.ov_lb = ObsNormWrapper.override_bounds(lb, self.explicit_lb, wos.labels)
-        self.ov_ub = ObsNormWrapper.override_bounds(ub, self.explicit_ub, wos.labels)
-        if any(self.ov_lb == -np.inf):
-            raise ValueErr(msg=f"At least one element of the lower bounds is (negative) infinite:\n"
-                               f"(overwritten) bound: {self.ov_lb}\nnames: {wos.labels}")
-        if any(self.ov_ub == np.inf):
-            raise ValueErr(msg=f"At least one element of the upper bound is (positive) infinite:\n"
-                               f"(overwritten) bound: {self.ov_ub}\nnames: {wos.labels}")
+        self.explicit_lb, self.explicit_ub = explicit_lb, explicit_ub
+        space = self.wrapped_env.obs_space
+        lo, up = space.bounds
+        self.ov_lb = self.override_bounds(lo, explicit_lb, space.labels)
+        self.ov_ub = self.override_bounds(up, explicit_ub, space.labels)
+        for which, vec, bad in (("lower bounds is (negative)", self.ov_lb, -np.inf), ("upper bound is (positive)", self.ov_ub, np.inf)):
+            if np.any(vec == bad):
+                raise ValueErr(msg=f"At least one element of the {which} infinite:\n(overwritten) bound: {vec}\n"
+                                   f"names: {space.labels}")
 
     @staticmethod
     def override_bounds(bounds: np.ndarray, override, names: np.ndarray) -> np.ndarray:
+        """a copy of `bounds` with the labelled entries of `override` put in; without an override dict the array itself"""
         if not override:
             return bounds
-        bc = bounds.copy()
-        for idx, name in np.ndenumerate(names):
-            ov = override.get(name)
-            if ov is not None:
-                bc[idx] = ov
-            elif np.isinf(bc[idx]):
-                raise ValueErr(msg=f"The entry {name} of a bound is infinite and not overwritten. Cannot apply normalization!")
-        return bc
+        out = np.array(bounds, dtype=float, copy=True)
+        given = np.array([override.get(lab) is not None for lab in names.ravel()]).reshape(names.shape)
+        loose = np.isinf(out) & ~given
+        if loose.any():
+            raise ValueErr(msg=f"The entry {names[loose].ravel()[0]} of a bound is infinite and not overwritten. "
+                               f"Cannot apply normalization!")
+        out[given] = [override[lab] for lab in names[given].ravel()]
+        return out
 
     def _process_obs(self, obs: np.ndarray) -> np.ndarray:
-        return (obs - self.ov_lb) / (self.ov_ub - self.ov_lb) * 2 - 1
+        span = self.ov_ub - self.ov_lb
+        return (obs - self.ov_lb) / span * 2 - 1
 
     def _process_obs_space(self, space):
         from .spaces import BoxSpace
 
         if not isinstance(space, BoxSpace):
             raise NotImplementedError("Only implemented ObsNormWrapper._process_obs_space() for BoxSpace!")
-        return BoxSpace(-np.ones(space.shape), np.ones(space.shape), labels=space.labels)
+        one = np.ones(space.shape)
+        return BoxSpace(-one, one, labels=space.labels)
 
 
 class ObsPartialWrapper(EnvWrapperObs):
