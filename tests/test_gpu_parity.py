@@ -951,3 +951,29 @@ def test_rollout_variant_selection(vs):
         x.set_rollout_variant("k_rollout_ws")
         assert x.rollout_variant() == ("k_rollout" if name == "qcp-st" else "k_rollout_ws")
         x.close()
+
+
+def test_baseline_config1_omo_single_env_500_steps(vs, golden_dir):
+    """BASELINE.json configs[0] on the device: ONE OneMassOscillatorSim, reset(init_state=[-0.7, 0]), the reference's 500
+    actions, forward Euler; the whole closed-loop trajectory against the reference's (a stable linear system: fp32 rounding
+    does not amplify), rewards, the once-only failure malus and the done mask; through vs_step and through the env object"""
+    L = vs._lib
+    g = np.load(os.path.join(golden_dir, "cfg1_omo_500.npz"))
+    env = vs.VecSimEnv("omo", 1, dt=0.02, max_steps=500)
+    env.reset(init_state=f32([[-0.7, 0.0]]))
+    np.testing.assert_allclose(env.get(L.VS_OBS)[0], g["obs0"], rtol=1e-6)
+    obj = vs.OneMassOscillatorSim(dt=0.02, max_steps=500)
+    obs = obj.reset(init_state=np.array([-0.7, 0.0]))
+    np.testing.assert_allclose(obs, g["obs0"], rtol=1e-6)
+    for t in range(500):
+        env.step(dev(g["act"][t][None, :]))
+        s = env.get(L.VS_STATE)[0]
+        np.testing.assert_allclose(s, g["state"][t + 1], rtol=2e-4, atol=2e-4, err_msg=f"t={t}")
+        np.testing.assert_allclose(env.get(L.VS_REW)[0], g["rew"][t], rtol=5e-4, atol=1e-5, err_msg=f"t={t}")
+        assert bool(env.get(L.VS_DONE)[0]) == bool(g["done"][t]), t
+        if t < 80:  # the env object: the same values through the reference-shaped surface
+            o2, r2, d2, _ = obj.step(g["act"][t].copy())
+            assert np.array_equal(o2.astype(np.float32), s) and d2 == bool(g["done"][t])
+            assert np.float32(r2) == env.get(L.VS_REW)[0]
+    assert int(env.get(L.VS_STEPCOUNT)[0]) == 500 and env.error_count() == 0
+    env.close()
