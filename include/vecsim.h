@@ -148,6 +148,10 @@ int vs_version(void);
 int vs_create(int env_type, int64_t n_envs, double dt, int64_t max_steps, int device_id, const vs_task_cfg* cfg,
               vs_handle* out);
 int vs_destroy(vs_handle h);
+/* `env.max_steps = n` / `env.dt = h` (P/environments/base.py:73-104): plain attribute updates in the reference -- state,
+ * step counters and running episodes are left alone; the new values apply from the next step.  max_steps <= 0: inf. */
+int vs_set_max_steps(vs_handle h, int64_t max_steps);
+int vs_set_dt(vs_handle h, double dt);
 /* Streams.  A handle launches on its own stream, created as a blocking stream (hipStreamDefault): it is implicitly
  * ordered with the legacy default stream (torch's default "current stream"), so default-stream work may read the
  * handle's buffers (vs_get) after a launch without further synchronisation.  A caller that runs on another,

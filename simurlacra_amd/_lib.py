@@ -36,6 +36,8 @@ _SIGNATURES = {
     "vs_nominal_params": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "vs_create": (C.c_int, [C.c_int, C.c_int64, C.c_double, C.c_int64, C.c_int, C.POINTER(TaskCfg), C.POINTER(_P)]),
     "vs_destroy": (C.c_int, [_P]),
+    "vs_set_max_steps": (C.c_int, [_P, C.c_int64]),
+    "vs_set_dt": (C.c_int, [_P, C.c_double]),
     "vs_set_stream": (C.c_int, [_P, _P]),
     "vs_sync": (C.c_int, [_P]),
     "vs_n_envs": (C.c_int64, [_P]),

@@ -1714,6 +1714,19 @@ int vs_reset(vs_handle h, const float* init_state, int64_t pitch, int full, cons
     return VS_OK;
 }
 
+int vs_set_max_steps(vs_handle h, int64_t max_steps) {
+    if (!h) return VS_ERR_ARG;
+    h->task.max_steps = (max_steps <= 0 || max_steps >= INT_MAX) ? INT_MAX : (int)max_steps;
+    return VS_OK;
+}
+
+int vs_set_dt(vs_handle h, double dt) {
+    if (!h) return VS_ERR_ARG;
+    if (!(dt >= 0.0)) return fail(h, VS_ERR_ARG, "vs_set_dt: dt must be >= 0");
+    h->task.dt = (float)dt;  // no derived constant depends on the step size
+    return VS_OK;
+}
+
 int vs_set_index_offset(vs_handle h, uint32_t first_global_index) {
     if (!h) return VS_ERR_ARG;
     h->d.idx0 = first_global_index;

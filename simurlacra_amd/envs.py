@@ -142,7 +142,8 @@ class VecSimPyEnv(SimEnv):
             raise TypeErr(given=dt, expected_type=[float, int])
         self._dt = float(dt)
         self._ctor["dt"] = dt
-        self._drop_handle()
+        if self._vec is not None:
+            self._vec.set_dt(self._dt)  # like the reference's attribute assignment: the state stays
 
     @property
     def max_steps(self):
@@ -157,7 +158,8 @@ class VecSimPyEnv(SimEnv):
         if num_steps != self._max_steps:
             self._max_steps = num_steps
             self._ctor["max_steps"] = num_steps
-            self._drop_handle()
+            if self._vec is not None:
+                self._vec.set_max_steps(num_steps)  # like the reference's attribute assignment: the state stays
 
     def _drop_handle(self):
         if self._vec is not None:

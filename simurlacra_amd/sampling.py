@@ -85,10 +85,14 @@ class StepSequence:
 
 
 def rollout(env, policy, eval: bool = False, max_steps: Optional[int] = None, reset_kwargs: Optional[dict] = None,
-            stop_on_done: bool = True, seed: Optional[int] = None, sub_seed: Optional[int] = None,
-            sub_sub_seed: Optional[int] = None) -> StepSequence:
+            render_mode=None, render_step: int = 1, no_reset: bool = False, no_close: bool = False,
+            record_dts: bool = False, stop_on_done: bool = True, seed: Optional[int] = None,
+            sub_seed: Optional[int] = None, sub_sub_seed: Optional[int] = None) -> StepSequence:
     """One rollout of ONE environment object through its reset()/step() surface (rollout.py:63-342): the reference's
-    loop, one kernel launch per step.  For throughput use ParallelRolloutSampler, which batches rollouts as lanes."""
+    loop and keyword arguments (rendering is a no-op for these simulations), one kernel launch per step.  For throughput
+    use ParallelRolloutSampler, which batches rollouts as lanes."""
+    import time
+
     import torch
 
     if not (isinstance(reset_kwargs, dict) or reset_kwargs is None):
@@ -97,12 +101,19 @@ def rollout(env, policy, eval: bool = False, max_steps: Optional[int] = None, re
         env.max_steps = max_steps
     if seed is not None:
         set_seed(seed, sub_seed, sub_sub_seed)
-    obs = env.reset(**(reset_kwargs or {}))
+    obs = np.zeros(env.obs_space.shape) if no_reset else env.reset(**(reset_kwargs or {}))
     if hasattr(policy, "reset"):
         policy.reset()
-    obs_hist, act_hist, rew_hist, state_hist, t_hist = [], [], [], [], [0.0]
-    done, t, steps = False, 0.0, 0
-    while not (done and stop_on_done) and steps < env.max_steps:
+    if hasattr(policy, "eval") and hasattr(policy, "train"):
+        policy.eval() if eval else policy.train()
+    env.render(render_mode, render_step=1)
+    obs_hist, act_hist, act_app_hist, rew_hist, state_hist, t_hist = [], [], [], [], [], [0.0]
+    dts = dict(dts_policy=[], dts_step=[], dts_remainder=[])
+    done, t = False, 0.0
+    t_post_step = time.time()  # the first remainder sample is meaningless, as in the reference
+    while not (done and stop_on_done) and env.curr_step < env.max_steps:
+        t_start = time.time()
+        dts["dts_remainder"].append(t_start - t_post_step)
         if np.isnan(obs).any():
             raise ValueErr(msg="At least one observation value is NaN!")
         with torch.no_grad():
@@ -110,27 +121,36 @@ def rollout(env, policy, eval: bool = False, max_steps: Optional[int] = None, re
         act = act.detach().cpu().numpy()
         if np.isnan(act).any():
             raise ValueErr(msg="At least one action value is NaN!")
+        t_post_policy = time.time()
+        dts["dts_policy"].append(t_post_policy - t_start)
         state = env.state.copy()
         obs_next, rew, done, _ = env.step(act)
+        act_app_hist.append(env.limit_act(act))
+        t_post_step = time.time()
+        dts["dts_step"].append(t_post_step - t_post_policy)
         obs_hist.append(np.asarray(obs))
         act_hist.append(act)
         rew_hist.append(rew)
         state_hist.append(state)
         t += env.dt
         t_hist.append(t)
+        env.render(render_mode, render_step)
         obs = obs_next
-        steps += 1
+    if not no_close:
+        env.close()  # nothing to disconnect from for a simulation; the device handle stays
     obs_hist.append(np.asarray(obs))
     state_hist.append(env.state.copy())
-    info = dict(env_name=env.name, domain_param=env.domain_param)
+    info = dict(env_name=env.name, env_spec=env.spec, domain_param=env.domain_param)
     # QCartPoleSim.reset returns the state instead of the observation (quirk Q5): keep lists when shapes differ
     try:
         observations = np.stack(obs_hist)
     except ValueError:
         observations = np.empty(len(obs_hist), dtype=object)
         observations[:] = obs_hist
+    extra = {k: np.asarray(v) for k, v in dts.items()} if record_dts else {}
     return StepSequence(observations=observations, actions=np.stack(act_hist), rewards=rew_hist,
-                        states=np.stack(state_hist), time=t_hist, rollout_info=info, done_last=bool(done))
+                        states=np.stack(state_hist), time=t_hist, rollout_info=info, done_last=bool(done),
+                        actions_applied=np.stack(act_app_hist), **extra)
 
 
 class ParallelRolloutSampler:

@@ -264,6 +264,17 @@ class VecSimEnv:
         self._check(self._lib.vs_set_param_buffer(self._h, soa.ctypes.data_as(C.c_void_p), soa.shape[1],
                                                   0 if selection == "cyclic" else 1), "vs_set_param_buffer")
 
+    def set_max_steps(self, max_steps):
+        """env.max_steps = ... : the running episodes and their step counters are untouched (vs_set_max_steps)"""
+        if max_steps < 1:
+            raise ValueErr(given=max_steps, ge_constraint="1")
+        self._check(self._lib.vs_set_max_steps(self._h, 0 if max_steps == math.inf else int(max_steps)), "vs_set_max_steps")
+        self.max_steps = max_steps
+
+    def set_dt(self, dt):
+        self._check(self._lib.vs_set_dt(self._h, float(dt)), "vs_set_dt")
+        self.dt = float(dt)
+
     def set_act_norm(self, on=True):
         """Fuse ActNormWrapper into the kernels: incoming actions are in [-1, 1]."""
         self._check(self._lib.vs_set_act_norm(self._h, int(bool(on))), "vs_set_act_norm")

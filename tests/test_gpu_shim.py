@@ -75,6 +75,19 @@ def test_rollout_loop_and_init_space(vs, name):
     assert 1 <= len(ro) <= 20 and ro.actions.shape == (len(ro), env.act_space.flat_dim)
     ro2 = rollout(env, DummyPolicy(env.spec), eval=True, seed=0, sub_seed=0, sub_sub_seed=1)
     assert np.array_equal(ro.rewards, ro2.rewards)  # set_seed -> same init state and actions
+    # the remaining keyword arguments of the reference's rollout(): per-step wall-clock splits, no_reset, stop_on_done
+    ro3 = rollout(env, DummyPolicy(env.spec), eval=True, seed=0, sub_seed=0, sub_sub_seed=1, record_dts=True, no_close=True)
+    assert np.array_equal(ro3.rewards, ro.rewards) and len(ro3.dts_policy) == len(ro3.dts_step) == len(ro3.dts_remainder) == len(ro3)
+    assert ro3.actions_applied.shape == ro3.actions.shape
+    lo, hi = env.act_space.bounds
+    assert (ro3.actions_applied >= lo - 1e-5).all() and (ro3.actions_applied <= hi + 1e-5).all()
+    state_before = env.state.copy()
+    # continue where the last rollout stopped: no reset, zero first observation; raising max_steps keeps state and step count
+    ro4 = rollout(env, DummyPolicy(env.spec), no_reset=True, stop_on_done=False, max_steps=len(ro3) + 5)
+    assert len(ro4) == 5 and np.array_equal(ro4.states[0], state_before) and env.curr_step == len(ro3) + 5
+    assert not ro4.observations[0].any()
+    env.dt = 2 * env.dt  # also a plain attribute in the reference
+    assert np.array_equal(env.state, ro4.states[-1]) and env.curr_step == len(ro3) + 5
     # test_reset: the same init state gives the same first observation
     s0 = env.init_space.sample_uniform()
     assert np.array_equal(env.reset(init_state=s0), env.reset(init_state=s0))
