@@ -22,3 +22,22 @@ def register_with_pyrado() -> bool:
     PyradoEnv.register(EnvWrapper)
     PyradoEnvWrapper.register(EnvWrapper)
     return True
+
+
+def to_pyrado_step_sequence(ro):
+    """One rollout of this package's sampler as Pyrado's own `StepSequence` (P/sampling/step_sequence.py:223-362), so that
+    Pyrado's algorithms (`StepSequence.concat`, `gae_returns`, `split_shuffled_batches`, ...) consume GPU rollouts
+    unchanged.  Needs Pyrado importable; raises ImportError otherwise."""
+    from pyrado.sampling.step_sequence import StepSequence as PyradoStepSequence
+
+    extra = {}
+    if getattr(ro, "states", None) is not None:
+        extra["states"] = ro.states
+    if getattr(ro, "time", None) is not None:
+        extra["time"] = ro.time
+    return PyradoStepSequence(observations=ro.observations, actions=ro.actions, rewards=ro.rewards,
+                              rollout_info=ro.rollout_info, complete=ro.complete, **extra)
+
+
+def to_pyrado_step_sequences(ros) -> list:
+    return [to_pyrado_step_sequence(ro) for ro in ros]

@@ -315,6 +315,27 @@ def test_register_with_pyrado_when_the_reference_is_importable():
         env = make("qq-su")
         w = vs.DomainRandWrapperLive(env, vs.create_default_randomizer(env))
         assert isinstance(env, PyradoSimEnv) and isinstance(pyrado_inner_env(w), PyradoSimEnv)
+        # rollouts of this package as Pyrado's own StepSequence: what its algorithms call on them
+        from pyrado.sampling.step_sequence import StepSequence as PyradoStepSequence
+        from pyrado.sampling.step_sequence import discounted_values, gae_returns
+
+        from simurlacra_amd.pyrado_compat import to_pyrado_step_sequences
+
+        rng = np.random.default_rng(0)
+        mine = [StepSequence._packed(rng.normal(size=(T + 1, 6)).astype(np.float32), rng.normal(size=(T, 1)).astype(np.float32),
+                                     rng.uniform(size=T).astype(np.float32), dict(env_name="qq-su"), True, 0.004, np.zeros(4))
+                for T in (5, 9, 3)]
+        theirs = to_pyrado_step_sequences(mine)
+        assert all(isinstance(r, PyradoStepSequence) for r in theirs)
+        for a, b in zip(mine, theirs):
+            assert b.length == len(a) and b.undiscounted_return() == pytest.approx(a.undiscounted_return(), rel=1e-12)
+            assert b.discounted_return(0.9) == pytest.approx(a.discounted_return(0.9), rel=1e-6)
+            assert b.done[-1] and not b.done[:-1].any() and b.rollout_info["env_name"] == "qq-su"
+        cat = PyradoStepSequence.concat(theirs)
+        assert cat.length == 17 and list(cat.rollout_lengths) == [5, 9, 3]
+        cat.torch()
+        assert discounted_values(theirs, 0.9).shape[0] == 17
+        assert len(list(cat.iterate_rollouts())) == 3
     finally:
         for k in list(sys.modules):
             if k not in saved:
