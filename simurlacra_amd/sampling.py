@@ -32,7 +32,10 @@ NO_SEED = object()
 
 class StepSequence:
     """Rollout container: observations [T+1, O], actions [T, A], rewards [T], optionally states [T+1, S].
-    The subset of P/sampling/step_sequence.py that samplers and on-policy algorithms touch."""
+    The subset of P/sampling/step_sequence.py that samplers and on-policy algorithms touch
+    (`simurlacra_amd.pyrado_compat.to_pyrado_step_sequence` gives Pyrado's full class when it is installed).
+    `time`, `done` and `rollout_info` of a sampler-made rollout are materialised on first access: building 4 096 of these
+    per `sample()` call is host work that would otherwise cost as much as the GPU part."""
 
     def __init__(self, *, observations, actions, rewards, states=None, time=None, rollout_info=None, env_infos=None,
                  complete=True, done_last=True, **extra):
@@ -42,37 +45,58 @@ class StepSequence:
         if not (len(self.observations) == len(self.actions) + 1 == len(self.rewards) + 1):
             raise ValueErr(msg="observations need one entry more than actions and rewards")
         self.states = None if states is None else np.asarray(states)
-        self.time = np.asarray(time) if time is not None else None
-        self.rollout_info = rollout_info or {}
+        self._time = np.asarray(time) if time is not None else None
+        self._dt = None
+        self._info = rollout_info or {}
+        self._info_src = None
         self.env_infos = env_infos
         self.complete = complete
-        self.done = np.zeros(len(self.rewards), dtype=bool)
-        if len(self.done) and done_last:
-            self.done[-1] = True
+        self._done = None
+        self._done_last = bool(done_last)
         for k, v in extra.items():
             setattr(self, k, v)
 
     @classmethod
-    def _packed(cls, observations, actions, rewards, rollout_info, done_last, dt, init_state):
-        """views into the sampler's packed arrays: no copies, no validation"""
+    def _packed(cls, observations, actions, rewards, info_src, done_last, dt, init_state):
+        """views into the sampler's packed arrays (rewards already float64): no copies, no validation.
+        info_src = (env_name, param_names, params_row, rollout_number)"""
         ro = cls.__new__(cls)
-        ro.observations, ro.actions = observations, actions
-        ro.rewards = rewards.astype(np.float64)
-        ro.states, ro.env_infos, ro.complete = None, None, True
-        ro.rollout_info = rollout_info
-        ro.time = np.arange(len(rewards) + 1) * dt
-        ro.done = np.zeros(len(rewards), dtype=bool)
-        if len(rewards) and done_last:
-            ro.done[-1] = True
+        ro.observations, ro.actions, ro.rewards = observations, actions, rewards
+        ro.states = ro.env_infos = ro._time = ro._done = ro._info = None
+        ro.complete = True
+        ro._info_src = info_src
+        ro._dt = dt
+        ro._done_last = done_last
         ro.init_state = init_state
         return ro
+
+    @property
+    def time(self):
+        if self._time is None and self._dt is not None:
+            self._time = np.arange(len(self.rewards) + 1) * self._dt
+        return self._time
+
+    @property
+    def done(self) -> np.ndarray:
+        if self._done is None:
+            self._done = np.zeros(len(self.rewards), dtype=bool)
+            if len(self._done) and self._done_last:
+                self._done[-1] = True
+        return self._done
+
+    @property
+    def rollout_info(self) -> dict:
+        if self._info is None:
+            name, pnames, row, number = self._info_src
+            self._info = dict(env_name=name, domain_param=dict(zip(pnames, row.tolist())), rollout_number=number)
+        return self._info
 
     @property
     def length(self) -> int:
         return len(self.rewards)
 
     def __len__(self):
-        return self.length
+        return len(self.rewards)
 
     def undiscounted_return(self) -> float:
         return float(np.sum(self.rewards))
@@ -308,9 +332,15 @@ class ParallelRolloutSampler:
                 if bool(done_t.bool().all()):  # one scalar sync per launch
                     break
             v.set_traj_offset(0)
-            tt = v.traj_tensors(t, n)
-            obs_T, act_T = visible(tt["obs"], 2), tt["act"]  # [T, n, dim]
-            rew_T, done_T = tt["rew"], tt["done"].bool()  # [T, n]
+            F_rec = v.traj_layout()[0]
+            done_T = v.traj_planes()[1][:t, :n].bool()  # [T, n]
+
+            def gather(ti, li):  # only the steps that belong to a rollout are ever read from the record planes
+                rec = v.gather_traj(ti, li)
+                return visible(rec[:, :O], 1), rec[:, O:O + A], rec[:, F_rec - 1]
+
+            def final_obs(length, T):  # lanes freeze at done: VS_OBS is the observation after every lane's last step
+                return visible(obs_full, 0).t()
         else:
             policy = self.policy.to(dev) if hasattr(self.policy, "to") else self.policy
             if hasattr(policy, "eval"):
@@ -333,6 +363,14 @@ class ParallelRolloutSampler:
                             break
             obs_T, act_T = torch.stack(obs_rec), torch.stack(act_rec)  # [T, n, dim]
             rew_T, done_T = torch.stack(rew_rec), torch.stack(done_rec).bool()
+
+            def gather(ti, li):
+                return obs_T[ti, li], act_T[ti, li], rew_T[ti, li]
+
+            def final_obs(length, T):  # vs_step keeps stepping finished lanes: take the observation recorded at t = length
+                ar_ = torch.arange(n, device=dev)
+                seen = obs_T[torch.clamp(length, max=T - 1), ar_]
+                return torch.where((length < T)[:, None], seen, visible(obs_full, 0).t())
         v.raise_on_error()
         # ---- split into rollouts on the device: rollout j = steps 0 .. first done of lane j, packed lane-major ----
         T = t
@@ -340,28 +378,48 @@ class ParallelRolloutSampler:
         any_done = done_T.any(dim=0)
         first = torch.where(any_done, done_T.to(torch.uint8).argmax(dim=0), torch.full_like(ar, T - 1))
         length = first + 1  # [n]
-        tgrid = torch.arange(T + 1, device=dev)[None, :]
-        mask = tgrid[:, :T] < length[:, None]  # [n, T]
-        mask_o = tgrid <= length[:, None]  # [n, T + 1]: one observation more than steps
-        obs_ext = torch.cat([obs_T, visible(obs_full, 0).t()[None]], dim=0)  # the row after the last step: the current obs
-        obs_p = obs_ext.permute(1, 0, 2)[mask_o].cpu().numpy()
-        act_p = act_T.permute(1, 0, 2)[mask].cpu().numpy()
-        rew_p = rew_T.t()[mask].cpu().numpy()
-        done_last = done_T[first, ar].cpu().numpy()
-        length_h = length.cpu().numpy()
-        state0_h = state0.cpu().numpy()
+        total = int(length.sum())  # the one size-dependent sync
+        lane = torch.repeat_interleave(ar, length, output_size=total)  # packed step k belongs to lane[k] ...
+        start = torch.cumsum(length, 0) - length
+        k_idx = torch.arange(total, device=dev)
+        t_idx = k_idx - start[lane]  # ... at time t_idx[k]
+        obs_s, act_s, rew_s = gather(t_idx, lane)
+        obs_all = torch.empty(total + n, obs_s.shape[1], device=dev)  # one observation more than steps per rollout
+        obs_all[k_idx + lane] = obs_s
+        obs_all[start + length + ar] = final_obs(length, T)
+        # device -> host through pinned staging buffers (a pageable .cpu() of ~70 MB runs at ~3 GB/s here), then one memcpy
+        # each into arrays the caller owns
+        obs_p, act_p, rew_h, done_h, length_h, state0_h = self._to_host(
+            [obs_all, act_s.contiguous(), rew_s.contiguous(), done_T[first, ar].to(torch.uint8), length, state0.contiguous()])
+        rew_p = rew_h.astype(np.float64)  # one conversion for all rollouts
+        done_last = done_h.astype(bool).tolist()
         params = v.get(L.VS_PARAMS)
-        off = np.concatenate([[0], np.cumsum(length_h)])
-        off_o = np.concatenate([[0], np.cumsum(length_h + 1)])
-        dt = base.dt
-        ros = []
-        for j in range(n):
-            Lj = int(length_h[j])
-            info = dict(env_name=base.name, domain_param=dict(zip(v.param_names, params[j].tolist())),
-                        rollout_number=first_index + j)
-            ros.append(StepSequence._packed(obs_p[off_o[j]:off_o[j + 1]], act_p[off[j]:off[j + 1]], rew_p[off[j]:off[j + 1]],
-                                            info, bool(done_last[j]), dt, state0_h[j]))
+        off = np.concatenate([[0], np.cumsum(length_h)]).tolist()
+        off_o = np.concatenate([[0], np.cumsum(length_h + 1)]).tolist()
+        dt, name, pnames = base.dt, base.name, v.param_names
+        packed = StepSequence._packed
+        ros = [packed(obs_p[off_o[j]:off_o[j + 1]], act_p[off[j]:off[j + 1]], rew_p[off[j]:off[j + 1]],
+                      (name, pnames, params[j], first_index + j), done_last[j], dt, state0_h[j]) for j in range(n)]
         return ros
+
+    def _to_host(self, tensors):
+        """copies of device tensors as NumPy arrays: asynchronous copies into cached pinned buffers, one sync, one memcpy"""
+        import torch
+
+        if not hasattr(self, "_pinned"):
+            self._pinned = {}
+        staged = []
+        for k, t in enumerate(tensors):
+            nbytes = t.numel() * t.element_size()
+            buf = self._pinned.get(k)
+            if buf is None or buf.numel() < nbytes:
+                buf = torch.empty(max(int(nbytes * 1.25), 1 << 16), dtype=torch.uint8, pin_memory=True)
+                self._pinned[k] = buf
+            view = buf[:nbytes].view(t.dtype).view(t.shape)
+            view.copy_(t, non_blocking=True)
+            staged.append(view)
+        torch.cuda.current_stream(tensors[0].device).synchronize()
+        return [v.numpy().copy() for v in staged]
 
     def sample(self, init_states: Optional[List[np.ndarray]] = None, domain_params: Optional[List[dict]] = None,
                eval: bool = False) -> List[StepSequence]:

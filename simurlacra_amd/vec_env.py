@@ -403,6 +403,31 @@ class VecSimEnv:
         self._check(self._lib.vs_traj_layout(L.ENV_TYPES[self.name], *[C.byref(x) for x in v]), "vs_traj_layout")
         return tuple(x.value for x in v)
 
+    def traj_planes(self):
+        """zero-copy views of the record buffer: [(plane [T_cap, ld, w], first record column)], done [T_cap, ld] u8"""
+        import torch
+
+        F, nq, h2, h1 = self.traj_layout()
+        ld, dev = self.ld, f"cuda:{self.device}"
+        ptr = self._lib.vs_get(self._h, L.VS_TRAJ_REC)
+        rows = torch.as_tensor(_DevArray(ptr, (self._traj_cap, F * ld), "<f4", self), device=dev)
+        planes, off, col = [], 0, 0
+        for w, count in ((4, nq), (2, h2), (1, h1)):
+            for _ in range(count):
+                planes.append((rows[:, off:off + w * ld].view(self._traj_cap, ld, w), col))
+                off += w * ld
+                col += w
+        dptr = self._lib.vs_get(self._h, L.VS_TRAJ_DONE)
+        done = torch.as_tensor(_DevArray(dptr, (self._traj_cap, ld), "|u1", self), device=dev)
+        return planes, done
+
+    def gather_traj(self, t_idx, lane_idx):
+        """records [len(t_idx), F] of the (step, env) pairs given by two index tensors: reads only what is asked for"""
+        import torch
+
+        planes, _ = self.traj_planes()
+        return torch.cat([p[t_idx, lane_idx] for p, _ in planes], dim=1)
+
     def traj_tensors(self, k_steps=None, n=None):
         """The recorded steps as torch tensors on the device: dict(obs [T, n, O], act [T, n, A], rew [T, n], done [T, n] u8).
         `rec` ([T, n, F], one gather of the record planes) is the only copy; obs / act / rew are views of it, done is a
@@ -411,20 +436,11 @@ class VecSimEnv:
 
         T = self._traj_cap if k_steps is None else int(k_steps)
         n = self.n_envs if n is None else int(n)
-        F, nq, h2, h1 = self.traj_layout()
-        O, A, ld = self.dims["O"], self.dims["A"], self.ld
-        dev = f"cuda:{self.device}"
-        ptr = self._lib.vs_get(self._h, L.VS_TRAJ_REC)
-        rows = torch.as_tensor(_DevArray(ptr, (self._traj_cap, F * ld), "<f4", self), device=dev)[:T]
-        parts, off = [], 0
-        for w, count in ((4, nq), (2, h2), (1, h1)):
-            for _ in range(count):
-                parts.append(rows[:, off:off + w * ld].view(T, ld, w)[:, :n])
-                off += w * ld
-        rec = torch.cat(parts, dim=2)  # [T, n, F]
-        dptr = self._lib.vs_get(self._h, L.VS_TRAJ_DONE)
-        done = torch.as_tensor(_DevArray(dptr, (self._traj_cap, ld), "|u1", self), device=dev)[:T, :n]
-        return dict(rec=rec, obs=rec[..., :O], act=rec[..., O:O + A], rew=rec[..., F - 1], done=done)
+        F = self.traj_layout()[0]
+        O, A = self.dims["O"], self.dims["A"]
+        planes, done = self.traj_planes()
+        rec = torch.cat([p[:T, :n] for p, _ in planes], dim=2)  # [T, n, F]
+        return dict(rec=rec, obs=rec[..., :O], act=rec[..., O:O + A], rew=rec[..., F - 1], done=done[:T, :n])
 
     def step_random(self, k_steps=1, seed=0, record=False):
         if record and getattr(self, "_traj_t0", 0) + k_steps > self._traj_cap:

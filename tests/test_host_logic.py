@@ -323,7 +323,7 @@ def test_register_with_pyrado_when_the_reference_is_importable():
 
         rng = np.random.default_rng(0)
         mine = [StepSequence._packed(rng.normal(size=(T + 1, 6)).astype(np.float32), rng.normal(size=(T, 1)).astype(np.float32),
-                                     rng.uniform(size=T).astype(np.float32), dict(env_name="qq-su"), True, 0.004, np.zeros(4))
+                                     rng.uniform(size=T), ("qq-su", ["g"], np.array([9.81]), 7), True, 0.004, np.zeros(4))
                 for T in (5, 9, 3)]
         theirs = to_pyrado_step_sequences(mine)
         assert all(isinstance(r, PyradoStepSequence) for r in theirs)
