@@ -739,7 +739,9 @@ __global__ __launch_bounds__(WS_BLOCK) void k_rollout_ws(Task T, Dev d, int k_st
         ws_barrier();  // the actions of batch 0 are in l_act[0]
         for (int b = 0; b < nb; ++b) {
             const int nr = min(WS_R, k_steps - b * WS_R);
-            for (int r = 0; r < nr; ++r) {
+#pragma unroll
+            for (int r = 0; r < WS_R; ++r) {
+                if (r >= nr) break;
                 float a[E::A];
                 Planes<E::A>::load(l_act[b & 1][r], WS_ENVS, le, a);
                 float v[M];
@@ -830,7 +832,9 @@ __global__ __launch_bounds__(WS_BLOCK) void k_rollout_ws(Task T, Dev d, int k_st
         // the actions of batch bb: act_space.sample_uniform() per step, the very stream of k_rollout
         auto draw = [&](int bb) {
             const int nr = min(WS_R, k_steps - bb * WS_R);
-            for (int r = 0; r < nr; ++r) {
+#pragma unroll
+            for (int r = 0; r < WS_R; ++r) {
+                if (r >= nr) break;
                 const int t = bb * WS_R + r;
                 uint64_t ta = epoch0 + (uint64_t)t;
                 unsigned sub = (unsigned)(ta % SPB);
@@ -849,7 +853,9 @@ __global__ __launch_bounds__(WS_BLOCK) void k_rollout_ws(Task T, Dev d, int k_st
         // reward, returns and records of the steps of batch bb
         auto work_off = [&](int bb) {
             const int nr = min(WS_R, k_steps - bb * WS_R);
-            for (int r = 0; r < nr; ++r) {
+#pragma unroll
+            for (int r = 0; r < WS_R; ++r) {
+                if (r >= nr) break;
                 const int t = bb * WS_R + r;
                 float v[M], a[E::A];
                 Planes<M>::load(l_msg[bb & 1][r], WS_ENVS, le, v);
