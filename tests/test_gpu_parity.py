@@ -945,7 +945,7 @@ def test_rollout_variant_selection(vs):
     big = vs.VecSimEnv("qq-su", 131072, **KW["qq-su"])
     assert big.rollout_variant() == "k_rollout"
     big.close()
-    for name, expect in (("omo", "k_rollout"), ("qbb", "k_rollout"), ("qcp-st", "k_rollout"), ("bob", "k_rollout_ws")):
+    for name, expect in (("omo", "k_rollout_ws"), ("qbb", "k_rollout"), ("qcp-st", "k_rollout"), ("bob", "k_rollout_ws")):
         x = vs.VecSimEnv(name, 4096, **KW[name])
         assert x.rollout_variant() == expect, name
         x.set_rollout_variant("k_rollout_ws")
