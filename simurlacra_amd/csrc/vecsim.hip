@@ -698,6 +698,9 @@ constexpr int WS_BLOCK = 512, WS_ENVS = 256;
 enum : unsigned { WSF_DONE = 1u, WSF_FAILED = 2u, WSF_FROZEN = 4u, WSF_FIN = 8u };
 
 __device__ __forceinline__ void ws_barrier() {
+#ifdef VS_WS_NOSYNC  // diagnostic builds only (timing without the exchange; results are wrong)
+    return;
+#endif
     // LDS traffic only: wait for this wave's LDS ops (lgkmcnt(0)), not for its global stores (a __syncthreads() would also
     // drain vmcnt and stall the C wave on its record stores in every phase)
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -737,13 +740,20 @@ __global__ __launch_bounds__(WS_BLOCK) void k_rollout_ws(Task T, Dev d, int k_st
         if (REC) E::observe(s, ob);
         __builtin_amdgcn_s_waitcnt(0x0F70);
         ws_barrier();  // the actions of batch 0 are in l_act[0]
+#ifdef VS_WS_NOP  // diagnostic: the P wave only keeps the barriers
+        for (int b = 0; b < nb; ++b) ws_barrier();
+        if (false)
+#endif
         for (int b = 0; b < nb; ++b) {
             const int nr = min(WS_R, k_steps - b * WS_R);
+            // all actions of the batch up front: one LDS round trip per batch instead of one per step on the critical path
+            float a_all[WS_R][E::A];
+#pragma unroll
+            for (int r = 0; r < WS_R; ++r) Planes<E::A>::load(l_act[b & 1][r], WS_ENVS, le, a_all[r]);
 #pragma unroll
             for (int r = 0; r < WS_R; ++r) {
                 if (r >= nr) break;
-                float a[E::A];
-                Planes<E::A>::load(l_act[b & 1][r], WS_ENVS, le, a);
+                const float* a = a_all[r];
                 float v[M];
 #pragma unroll
                 for (int j = 0; j < E::S; ++j) v[j] = s[j];
@@ -910,6 +920,10 @@ __global__ __launch_bounds__(WS_BLOCK) void k_rollout_ws(Task T, Dev d, int k_st
         __builtin_amdgcn_s_waitcnt(0x0F70);
         draw(0);
         ws_barrier();
+#ifdef VS_WS_NOC  // diagnostic: the C wave only keeps the barriers
+        for (int b = 0; b < nb; ++b) ws_barrier();
+        if (false)
+#endif
         for (int b = 0; b < nb; ++b) {
             if (b >= 1) work_off(b - 1);  // reads l_act[(b - 1) & 1] before draw(b + 1) overwrites the same buffer
             if (b + 1 < nb) draw(b + 1);
