@@ -268,13 +268,15 @@ def main():
         achieved = b_per * units / (ms * 1e-3) / 1e9
         # the practical HBM ceiling next to the nominal one -- an in-repo float4 copy kernel (read + write of
         # 1 GiB per pass, far beyond the caches), timed with HIP events
-        copy_gbs = None
+        copy_gbs, write_gbs = None, None
         try:
             import ctypes
 
             g = ctypes.c_float()
             if L.load().vs_membw_probe(local_rank, 1 << 30, 10, ctypes.byref(g)) == 0:
                 copy_gbs = float(g.value)
+            if L.load().vs_memwrite_probe(local_rank, 1 << 30, 10, ctypes.byref(g)) == 0:
+                write_gbs = float(g.value)  # a pure write stream: what the record stores of the fused kernel compete with
         except Exception:
             pass
         # HBM bytes per launch from the PMC counters (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 passes of this very
@@ -307,7 +309,9 @@ def main():
                        "parallelism": f"env-shard x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "copy_kernel_GBs": copy_gbs,
-                         "frac_of_copy_kernel": (achieved / copy_gbs) if copy_gbs else None, "traffic": traffic, "traffic_unit": "bytes/launch (PMC)",
+                         "frac_of_copy_kernel": (achieved / copy_gbs) if copy_gbs else None,
+                         "write_kernel_GBs": write_gbs,
+                         "frac_of_write_kernel": (achieved / write_gbs) if write_gbs else None, "traffic": traffic, "traffic_unit": "bytes/launch (PMC)",
                          "traffic_source": traffic_src, "alg_bytes_per_launch": b_per * units, "kernel": kname,
                          "kernel_ms": ms, "alg_bytes_per_env_step": b_per, "env_steps_per_launch": units,
                          "note": ("at 65 536 envs there is one wave of envs per SIMD: the fused kernel is bound by VALU issue "

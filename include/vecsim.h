@@ -284,6 +284,8 @@ int vs_time_step_kernel(vs_handle h, int mode, const float* actions, int64_t env
                         int k_steps, int record, int iters, float* avg_ms);
 /* streaming copy kernel (float4) over `bytes` of device memory: achieved GB/s (in-repo HBM reference point) */
 int vs_membw_probe(int device_id, int64_t bytes, int iters, float* gbps);
+/* the same for a pure write stream (float4 stores): the ceiling of the record stream of vs_step_random */
+int vs_memwrite_probe(int device_id, int64_t bytes, int iters, float* gbps);
 
 #ifdef __cplusplus
 }

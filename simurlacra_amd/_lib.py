@@ -78,6 +78,7 @@ _SIGNATURES = {
     "vs_time_step_kernel": (C.c_int, [_P, C.c_int, _P, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int,
                                       C.POINTER(C.c_float)]),
     "vs_membw_probe": (C.c_int, [C.c_int, C.c_int64, C.c_int, C.POINTER(C.c_float)]),
+    "vs_memwrite_probe": (C.c_int, [C.c_int, C.c_int64, C.c_int, C.POINTER(C.c_float)]),
 }
 
 _lib = None

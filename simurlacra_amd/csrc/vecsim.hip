@@ -163,6 +163,18 @@ __device__ __forceinline__ R step_reward(const Task& T, const float* c, const R*
     return exp_neg_fast(-c[E::CMAX >= 0 ? E::CMAX : 0] * cost);
 }
 
+// not state_space.contains(s') (Q9, Q10) for a symmetric box: some |s_j| > hi_j  <=>  max_j (|s_j| - hi_j) > 0.
+// One compare at the end instead of one per dimension: every v_cmp feeds a scalar mask and a chain of s_or, and each
+// VALU -> SALU hand-over stalls a lone wave.  The differences are exact (|s| - hi is 0 or at least an ulp of values of order
+// 1..100, never subnormal); NaN dimensions drop out of the max (maxNum), as `NaN > hi` is false.
+template <int S>
+__device__ __forceinline__ bool outside_symmetric_box(const float* sv, const float* hi) {
+    float m = fabsf(sv[0]) - hi[0];
+#pragma unroll
+    for (int j = 1; j < S; ++j) m = fmaxf(m, fabsf(sv[j]) - hi[j]);
+    return m > 0.f;
+}
+
 template <class R>
 struct StepOutT {
     R rew;
@@ -215,14 +227,15 @@ __device__ __forceinline__ StepOutT<R> step_one(const Task& T, const float* c, R
     float slo[E::S], shi[E::S];
     E::state_bounds(c, slo, shi);
     o.failed = false;
+    float svv[E::S];
 #pragma unroll
     for (int j = 0; j < E::S; ++j) {
-        float sv = val(s[j]);
-        o.err |= isnan(sv);
-        // not state_space.contains(s') (Q9, Q10): s < lo or s > hi; most state boxes are symmetric (lo == -hi), so this
-        // is |s| > hi -- one compare with the abs modifier, NaN compares false as in NumPy
-        o.failed |= E::SYMMETRIC_BOX ? (fabsf(sv) > shi[j]) : ((sv < slo[j]) | (sv > shi[j]));
+        svv[j] = val(s[j]);
+        o.err |= isnan(svv[j]);
+        // not state_space.contains(s') (Q9, Q10): s < lo or s > hi, NaN compares false as in NumPy
+        if (!E::SYMMETRIC_BOX) o.failed |= (svv[j] < slo[j]) | (svv[j] > shi[j]);
     }
+    if (E::SYMMETRIC_BOX) o.failed = outside_symmetric_box<E::S>(svv, shi);
     o.done = o.failed | (step >= T.max_steps);
     if (E::FINAL != FINAL_NONE) {
         // FinalRewTask.compute_final_rew, paid once per episode (P/tasks/final_reward.py:130-135)
@@ -317,7 +330,7 @@ __device__ __forceinline__ void reset_lane_sampled(const Task& T, const Dev& d, 
 
 // completed-episode append with a wavefront ballot: one atomic per wave, lanes ranked by popcount of the lower mask
 __device__ __forceinline__ void append_episode(const Dev& d, bool fin, int i, float ret, int len) {
-    unsigned long long m = __ballot(fin);
+    unsigned long long m = __builtin_amdgcn_ballot_w64(fin);
     if (m == 0ull) return;
     unsigned lane = __lane_id();
     int leader = __ffsll((long long)m) - 1;
@@ -345,7 +358,7 @@ struct EpStat {
 template <class E, bool UNI>
 __device__ __forceinline__ void auto_reset(const Task& T, const Dev& d, bool fin, int i, uint64_t seed, float* c,
                                            float* s, float* h, int& step, float& ret, bool& yielded, EpStat& es) {
-    if (__ballot(fin) == 0ull) return;
+    if (__builtin_amdgcn_ballot_w64(fin) == 0ull) return;
     if (d.log_episodes) append_episode(d, fin, i, ret, step);
     if (fin) {
         es.count += 1u;
@@ -395,7 +408,7 @@ __device__ __forceinline__ void step_body(const Task& T, const Dev& d, const flo
 
     if (AR) {
         bool fin = o.done && valid;
-        if (__ballot(fin) != 0ull) {  // single-step kernel: the per-env counters are touched by finishing lanes only
+        if (__builtin_amdgcn_ballot_w64(fin) != 0ull) {  // single-step kernel: the per-env counters are touched by finishing lanes only
             EpStat es{0u, 0u, 0.f, 0};
             if (fin) es = EpStat{d.ep_idx[i], d.es_count[i], d.es_retsum[i], d.es_lensum[i]};
             auto_reset<E, UNI>(T, d, fin, i, seed, c, s, h, step, ret, yielded, es);
@@ -641,7 +654,7 @@ __device__ __forceinline__ void rollout_body(const Task& T, const Dev& d, int k_
             frozen |= done;
             // early termination: a wave whose 64 rollouts have all ended has nothing left to do (the ballot is
             // wave-uniform, so the whole wave leaves the loop together); with records on it keeps writing its frozen rows
-            if (!REC && __ballot(!frozen) == 0ull) break;
+            if (!REC && __builtin_amdgcn_ballot_w64(!frozen) == 0ull) break;
         }
 #ifdef VS_ABLATE_OBSERVE
         if (REC) { for (int j = 0; j < E::O; ++j) ob[j] = s[j % E::S]; }
@@ -786,10 +799,10 @@ __global__ __launch_bounds__(WS_BLOCK) void k_rollout_ws(Task T, Dev d, int k_st
                     failed = false;
 #pragma unroll
                     for (int j = 0; j < E::S; ++j) {
-                        float sv = s[j];
-                        err |= isnan(sv);
-                        failed |= E::SYMMETRIC_BOX ? (fabsf(sv) > shi[j]) : ((sv < slo[j]) | (sv > shi[j]));
+                        err |= isnan(s[j]);
+                        if (!E::SYMMETRIC_BOX) failed |= (s[j] < slo[j]) | (s[j] > shi[j]);
                     }
+                    if (E::SYMMETRIC_BOX) failed = outside_symmetric_box<E::S>(s, shi);
                     done = failed | (step >= T.max_steps);
                     if (err && valid) d.err[i] = 1;
                     fin = done && valid;
@@ -800,7 +813,7 @@ __global__ __launch_bounds__(WS_BLOCK) void k_rollout_ws(Task T, Dev d, int k_st
                 if (M > M0) v[M - 1] = 0.f;
                 Planes<M>::store(l_msg[b & 1][r], WS_ENVS, le, v);
                 if (AR) {
-                    if (__ballot(fin) != 0ull) {
+                    if (__builtin_amdgcn_ballot_w64(fin) != 0ull) {
                         if (fin) {
                             load_consts<E, UNI>(d, i, c, E::KS, E::K);
                             // live domain randomisation redraws the lane's parameters here: allowed for the families
@@ -902,7 +915,7 @@ __global__ __launch_bounds__(WS_BLOCK) void k_rollout_ws(Task T, Dev d, int k_st
                     store_record<E>(d.traj_rec + (rec0 + (size_t)t) * Rec<E>::F * ld, ld, i, v + E::S, a, rew);
                     d.traj_done[(rec0 + (size_t)t) * ld + i] = done;
                 }
-                if (__ballot(fin) != 0ull) {
+                if (__builtin_amdgcn_ballot_w64(fin) != 0ull) {
                     if (d.log_episodes) append_episode(d, fin, i, ret, len);
                     if (fin) {
                         es.count += 1u;
@@ -1095,8 +1108,15 @@ __global__ __launch_bounds__(BLOCK) void k_observe(Dev d) {
 __global__ void k_count_err(const uint8_t* err, int n, unsigned long long* out) {
     int i = blockIdx.x * BLOCK + threadIdx.x;
     bool e = i < n && err[i] != 0;
-    unsigned long long m = __ballot(e);
+    unsigned long long m = __builtin_amdgcn_ballot_w64(e);
     if (__lane_id() == 0 && m) atomicAdd(out, (unsigned long long)__popcll(m));
+}
+
+__global__ void k_fill4(float4* __restrict__ dst, size_t n4, float v) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    const float4 x = make_float4(v, v + 1.f, v + 2.f, v + 3.f);
+    for (; i < n4; i += stride) dst[i] = x;
 }
 
 __global__ void k_copy4(const float4* __restrict__ src, float4* __restrict__ dst, size_t n4) {
@@ -2081,6 +2101,30 @@ int vs_membw_probe(int device_id, int64_t bytes, int iters, float* gbps) {
     (void)hipFree(b);
     if (e != hipSuccess || ms <= 0.f) return VS_ERR_HIP;
     *gbps = (float)(2.0 * (double)(n4 * 16) * iters / (ms * 1e-3) / 1e9);  // read + write
+    return VS_OK;
+}
+
+int vs_memwrite_probe(int device_id, int64_t bytes, int iters, float* gbps) {
+    if (!gbps || bytes < (1 << 20) || iters < 1) return VS_ERR_ARG;
+    if (hipSetDevice(device_id) != hipSuccess) return VS_ERR_HIP;
+    void* a = nullptr;
+    size_t n4 = (size_t)bytes / 16;
+    if (hipMalloc(&a, n4 * 16) != hipSuccess) return VS_ERR_HIP;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    hipLaunchKernelGGL(k_fill4, dim3(2048), dim3(256), 0, 0, (float4*)a, n4, 0.f);
+    (void)hipEventRecord(e0, 0);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(k_fill4, dim3(2048), dim3(256), 0, 0, (float4*)a, n4, (float)i);
+    (void)hipEventRecord(e1, 0);
+    hipError_t e = hipEventSynchronize(e1);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(a);
+    if (e != hipSuccess || ms <= 0.f) return VS_ERR_HIP;
+    *gbps = (float)((double)(n4 * 16) * iters / (ms * 1e-3) / 1e9);  // write only
     return VS_OK;
 }
 
