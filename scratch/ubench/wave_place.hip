@@ -1,6 +1,7 @@
 // where do the 8 waves of a 512-thread workgroup land?  HW_ID: wave_id[3:0] simd_id[5:4] pipe[7:6] cu_id[11:8] sh[12] se[15:13]
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 __global__ void k(unsigned* out) {
     unsigned id;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(id));
@@ -10,21 +11,21 @@ __global__ void k(unsigned* out) {
     // keep the wave alive a little so that all workgroups are resident together
     for (int i = 0; i < 2000; ++i) asm volatile("s_nop 15");
 }
-int main() {
-    unsigned* d; int blocks = 256, thr = 512, waves = blocks * thr / 64;
+int main(int argc, char** argv) {
+    unsigned* d; int blocks = 256, thr = argc > 1 ? atoi(argv[1]) : 512, waves = blocks * thr / 64;
     hipMalloc(&d, waves * 8);
     k<<<blocks, thr>>>(d);
     unsigned* h = new unsigned[waves * 2];
     hipMemcpy(h, d, waves * 8, hipMemcpyDeviceToHost);
-    int hist[4][2] = {}; int pairs_ok = 0;
+    int pairs_ok = 0; const int nw = thr / 64;
     for (int b = 0; b < blocks; ++b) {
-        int simd[8];
-        for (int w = 0; w < 8; ++w) simd[w] = (h[(b * 8 + w) * 2] >> 4) & 3;
+        int simd[16];
+        for (int w = 0; w < nw; ++w) simd[w] = (h[(b * nw + w) * 2] >> 4) & 3;
         bool ok = true;
-        for (int w = 0; w < 4; ++w) ok &= simd[w] == simd[w + 4];
+        for (int w = 4; w < nw; ++w) ok &= simd[w] == simd[w - 4];
         pairs_ok += ok;
-        if (b < 6) { printf("wg %d: simd", b); for (int w = 0; w < 8; ++w) printf(" %d", simd[w]); printf("  cu %u se %u xcc %u\n", (h[b * 16] >> 8) & 15, (h[b * 16] >> 13) & 7, h[b * 16 + 1] & 15); }
+        if (b < 6) { printf("wg %d: simd", b); for (int w = 0; w < nw; ++w) printf(" %d", simd[w]); printf("\n"); }
     }
-    printf("workgroups whose wave w and w+4 share a SIMD: %d of %d\n", pairs_ok, blocks);
+    printf("%d-thread workgroups whose wave w and w+4 (and w+8 ...) share a SIMD: %d of %d\n", thr, pairs_ok, blocks);
     return 0;
 }
