@@ -977,3 +977,63 @@ def test_baseline_config1_omo_single_env_500_steps(vs, golden_dir):
             assert np.float32(r2) == env.get(L.VS_REW)[0]
     assert int(env.get(L.VS_STEPCOUNT)[0]) == 500 and env.error_count() == 0
     env.close()
+
+
+def test_fused_kernels_fuzz_against_step_kernel(vs):
+    """seeded sweep over families, sizes, launch splits, constructor flags, ActNorm, per-env parameters and auto-reset:
+    k_rollout and k_rollout_ws must both reproduce the single-step kernel fed with their recorded actions, bit for bit"""
+    L = vs._lib
+    rng = np.random.default_rng(20260104)
+    names = ["omo", "bob", "qq-su", "qcp-su", "qbb", "qq-st", "pend", "bob-d"]
+    for case in range(24):
+        name = names[case % len(names)]
+        n = int(rng.choice([1, 63, 64, 257, 700, 1536]))
+        kw = dict(KW[name], max_steps=int(rng.integers(5, 40)))
+        extra = {}
+        if name == "qcp-su":
+            extra = dict(simple_dynamics=bool(rng.integers(2)), long=bool(rng.integers(2)),
+                         wild_init=str(rng.choice(["True", "False", "other"])))
+        if name == "qbb":
+            extra = dict(simple_dynamics=bool(rng.integers(2)))
+        auto_reset, act_norm, per_env = bool(rng.integers(2)), bool(rng.integers(2)), bool(rng.integers(2))
+        splits = [int(x) for x in rng.integers(1, 13, size=4)]
+        T = sum(splits)
+        ref = vs.VecSimEnv(name, n, **kw, **extra)
+        envs = {v: vs.VecSimEnv(name, n, **kw, **extra) for v in ("k_rollout", "k_rollout_ws")}
+        params = None
+        if per_env:
+            params = np.tile(vs.nominal_params(name, **({"long": extra["long"]} if "long" in extra else {})), (n, 1))
+            params *= 1.0 + 0.02 * rng.standard_normal(params.shape).astype(np.float32) * (params != 0)
+        for e in [ref, *envs.values()]:
+            if per_env:
+                e.set_params(params)
+            e.set_act_norm(act_norm)
+            e.set_auto_reset(auto_reset, seed=99)
+            e.reset(seed=case)
+        trajs = {}
+        for v, e in envs.items():
+            e.set_rollout_variant(v)
+            e.set_traj_capacity(T)
+            t = 0
+            for k in splits:
+                e.set_traj_offset(t)
+                e.step_random(k, seed=5, record=True)
+                t += k
+            trajs[v] = e.traj(T)
+        a, b = trajs["k_rollout"], trajs["k_rollout_ws"]
+        for key in ("obs", "act", "rew", "done"):
+            assert np.array_equal(a[key], b[key]), (case, name, key)
+        alive = np.ones(n, dtype=bool)
+        for t in range(T):
+            assert np.array_equal(ref.get(L.VS_OBS)[alive], a["obs"][t][alive]), (case, name, t)
+            ref.step(dev(a["act"][t]))
+            assert np.array_equal(ref.get(L.VS_REW)[alive], a["rew"][t][alive]), (case, name, t)
+            assert np.array_equal(ref.get(L.VS_DONE).astype(bool)[alive], a["done"][t].astype(bool)[alive])
+            if not auto_reset:
+                alive &= ~a["done"][t].astype(bool)
+        for which in (L.VS_STATE, L.VS_HIDDEN, L.VS_STEPCOUNT, L.VS_RETURNS):
+            x, y, z = (e.get(which) for e in (ref, envs["k_rollout"], envs["k_rollout_ws"]))
+            assert np.array_equal(y, z) and np.array_equal(x[alive], y[alive]), (case, name, which)
+        for e in [ref, *envs.values()]:
+            assert e.error_count() == 0
+            e.close()
