@@ -77,3 +77,22 @@ def test_bad_arguments(lib):
     assert lib.vs_create(2, 0, 0.004, 4000, 0, None, C.byref(h)) == L.VS_ERR_ARG
     assert lib.vs_create(2, 16, -1.0, 4000, 0, None, C.byref(h)) == L.VS_ERR_ARG
     assert lib.vs_env_dims(-1, None, None, None, None, None, None, None) == L.VS_ERR_ARG
+
+
+def test_plain_c_host_program_links_and_runs(lib, tmp_path):
+    """include/vecsim.h from C: compile tests/capi/capi_demo.c with gcc against libvecsim.so and run it (static tables
+    everywhere; on a GPU box also a fused rollout, here the loud no-GPU failure)"""
+    import shutil
+    import subprocess
+
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    exe = str(tmp_path / "capi_demo")
+    libdir = os.path.dirname(L.LIB_PATH)
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "capi", "capi_demo.c"), "-o", exe, "-L", libdir, "-l:libvecsim.so",
+                    "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "static tables ok" in out.stdout
+    assert ("no GPU: vs_create failed loudly" in out.stdout) or ("fused steps ok" in out.stdout)

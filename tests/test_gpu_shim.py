@@ -317,3 +317,22 @@ def test_param_buffer_on_device(vs, golden_dir):
         w.reset()
         seq.append([w.domain_param[k] for k in ("mass", "stiffness", "damping")])
     np.testing.assert_allclose(np.array(seq), g["omo_buffer_seq"], rtol=1e-15)
+
+
+def test_plain_c_host_program_runs_a_rollout(vs, tmp_path):
+    """the C-ABI from C on the GPU: tests/capi/capi_demo.c creates 4 096 envs, resets, runs 100 fused steps, copies the
+    state back (no Python, no torch in that process)"""
+    import shutil
+    import subprocess
+
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.dirname(vs._lib.LIB_PATH)
+    exe = str(tmp_path / "capi_demo")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(root, "include"),
+                    os.path.join(root, "tests", "capi", "capi_demo.c"), "-o", exe, "-L", libdir, "-l:libvecsim.so",
+                    "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "fused steps ok" in out.stdout
