@@ -336,3 +336,56 @@ def test_plain_c_host_program_runs_a_rollout(vs, tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "fused steps ok" in out.stdout
+
+
+@pytest.mark.parametrize("name", ["qbb", "bob"])
+def test_wrapper_combination_scenario_of_the_reference(vs, name):
+    """Pyrado/tests/environment_wrappers/test_combination.py:64-120 on env objects: a cyclic parameter buffer repeats after
+    its length, ObsNorm(ActNorm(env)) rollouts are the normalised plain rollouts, partial observations, action noise and an
+    action delay change the rollout the way that test expects (same seeds -> same policy actions)"""
+    from simurlacra_amd.policies import DummyPolicy
+    from simurlacra_amd.sampling import rollout
+
+    vs.set_seed(0)
+    env = vs.ENV_CLASSES[name](**KW[name])
+    env.max_steps = 20
+    env_r = vs.DomainRandWrapperBuffer(env, vs.create_default_randomizer(env))
+    env_r.fill_buffer(num_domains=3)
+    before, after = [], []
+    for i in range(4):
+        before.append(env_r.domain_param)
+        rollout(env_r, DummyPolicy(env_r.spec), eval=True, seed=0)
+        after.append(env_r.domain_param)
+        assert after[i] != before[i]
+    assert after[0] == after[3]
+
+    env.domain_param = type(env).get_nominal_domain_param()
+    env_n = vs.ActNormWrapper(env)
+    env_n = vs.ObsNormWrapper(env_n)  # all observation bounds of these two envs are finite
+    alb, aub = env_n.act_space.bounds
+    olb, oub = env_n.obs_space.bounds
+    assert all(alb == -1) and all(aub == 1) and all(olb == -1) and all(oub == 1)
+    plain = vs.ActNormWrapper(env)
+    ro_p = rollout(plain, DummyPolicy(plain.spec), eval=True, seed=0)
+    ro_n = rollout(env_n, DummyPolicy(env_n.spec), eval=True, seed=0)
+    assert np.allclose(env_n._process_obs(ro_p.observations), ro_n.observations, atol=1e-6)
+
+    labels = env.obs_space.labels
+    env_np = vs.ObsPartialWrapper(env_n, idcs=[labels[2], labels[3]])
+    ro_np = rollout(env_np, DummyPolicy(env_np.spec), eval=True, seed=0)
+    assert ro_np.observations.shape[1] == len(labels) - 2
+    keep = [j for j in range(len(labels)) if j not in (2, 3)]
+    assert np.allclose(ro_np.observations, ro_n.observations[:, keep], atol=1e-6)
+
+    env_npa = vs.GaussianActNoiseWrapper(env_np, noise_mean=0.5 * np.ones(env_np.act_space.shape),
+                                         noise_std=0.1 * np.ones(env_np.act_space.shape))
+    ro_npa = rollout(env_npa, DummyPolicy(env_npa.spec), eval=True, seed=0)
+    n = min(len(ro_np), len(ro_npa)) + 1
+    assert not np.allclose(ro_np.observations[:n], ro_npa.observations[:n])  # the action noise changed the rollout
+
+    env_npd = vs.ActDelayWrapper(env_np, delay=3)
+    ro_npd = rollout(env_npd, DummyPolicy(env_npd.spec), eval=True, seed=0)
+    n = min(len(ro_np), len(ro_npd))
+    assert np.allclose(ro_np.actions[:n], ro_npd.actions[:n])  # same policy actions ...
+    assert not np.allclose(ro_np.observations[:n + 1], ro_npd.observations[:n + 1])  # ... applied three steps later
+    assert type(vs.inner_env(env_npd)) is type(env) and vs.typed_env(env_npd, vs.ObsPartialWrapper) is not None
