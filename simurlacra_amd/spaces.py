@@ -217,6 +217,15 @@ class DiscreteSpace(Space):
     def num_ele(self) -> int:
         return self.eles.shape[0]
 
+    @staticmethod
+    def cat(spaces):
+        """the union of the element sets of several DiscreteSpaces, in order (P/spaces/discrete.py:133-160)"""
+        spaces = [s for s in spaces if s is not None]
+        for sp in spaces:
+            if not isinstance(sp, DiscreteSpace):
+                raise TypeErr(given=sp, expected_type=DiscreteSpace)
+        return DiscreteSpace(np.concatenate([sp.eles for sp in spaces], axis=0))
+
     @property
     def flat_dim(self) -> int:
         return self.eles.shape[1]
