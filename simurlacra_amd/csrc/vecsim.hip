@@ -4,6 +4,17 @@
 // wave is one contiguous 256-B segment.  The step of SimPyEnv (reward -> clip -> dead zone -> integrate -> done ->
 // final reward -> observe, P/environments/pysim/base.py:217-241) is ONE kernel; there is no CPU fallback anywhere:
 // every entry point either runs on the GPU or returns an error.
+//
+// Kernels:
+//   k_step          vs_step           one step per launch, actions from the caller (policy in the loop)
+//   k_rollout       vs_step_random    k steps per launch, on-device uniform policy, state in registers, optional records
+//   k_rollout_ws    vs_step_random    the same on two cooperating waves per 64 envs (physics | reward + records) through
+//                                     LDS: what runs while there is less than ~1.25 waves of envs per SIMD
+//   k_*_mixed       vs_mixed_*        several families in one launch (one workgroup = one family)
+//   k_step_jac      vs_step_jac       step + Jacobians by forward-mode dual numbers
+//   k_reset / k_set_params / k_sample_params / k_observe   control path
+// Variants carrying the wrapper pipeline (action noise / delay, observation normalisation / noise) are separate
+// instantiations (template parameter PIPE): the default kernels do not pay for it.
 #include <hip/hip_runtime.h>
 
 #include <climits>
