@@ -203,6 +203,12 @@ class ParallelRolloutSampler:
         if policy is not None:
             self.policy = policy
 
+    def set_min_count(self, min_rollouts=None, min_steps=None):
+        """SamplerBase.set_min_count (P/sampling/sampler.py): at least one of the two"""
+        if min_rollouts is None and min_steps is None:
+            raise ValueErr(msg="At least one of min_rollouts and min_steps must be given")
+        self.min_rollouts, self.min_steps = min_rollouts, min_steps
+
     # ------------------------------------------------------------------------------------------------ work list
     def work_list(self, init_states, domain_params):
         """[(init_state | None, domain_param | None)] in rollout order (parallel_rollout_sampler.py:280-304)"""
@@ -445,3 +451,45 @@ class ParallelRolloutSampler:
                     return out
             idx += nb
             guess = max(guess, int(len(out) * (self.min_steps / max(steps, 1) - 1)) + 1)
+
+
+def select_cvar(rollouts: list, epsilon: float, gamma: float = 1.0) -> list:
+    """The epsilon-fraction of the rollouts with the lowest discounted return, lowest first: their mean return is the
+    CVaR(eps) of the set (P/sampling/cvar_sampler.py:40-62).  Sorts `rollouts` in place, like the reference."""
+    rollouts.sort(key=lambda ro: ro.discounted_return(gamma))
+    keep = round(len(rollouts) * epsilon)
+    if keep == 0:
+        raise ValueErr(given=keep, g_constraint="0")
+    return rollouts[:keep]
+
+
+class CVaRSampler:
+    """Samples 1 / epsilon times as many rollouts with the wrapped sampler and keeps the worst epsilon-quantile (EPOpt;
+    P/sampling/cvar_sampler.py:65-140).  `full_stats` holds what the reference logs about the full set."""
+
+    def __init__(self, wrapped_sampler, epsilon: float, gamma: float = 1.0, *, min_rollouts: int = None,
+                 min_steps: int = None):
+        if not 0 < epsilon <= 1:
+            raise ValueErr(given=epsilon, g_constraint="0", le_constraint="1")
+        self._wrapped_sampler = wrapped_sampler
+        self.epsilon, self.gamma = epsilon, gamma
+        self.full_stats = {}
+        self.set_min_count(min_rollouts=min_rollouts, min_steps=min_steps)
+
+    def set_min_count(self, min_rollouts=None, min_steps=None):
+        if min_rollouts is None and min_steps is None:
+            raise ValueErr(msg="At least one of min_rollouts and min_steps must be given")
+        self.min_rollouts, self.min_steps = min_rollouts, min_steps
+        grow = lambda v: None if v is None else int(v / self.epsilon)  # the (1 - eps) quantile is thrown away
+        self._wrapped_sampler.set_min_count(min_rollouts=grow(min_rollouts), min_steps=grow(min_steps))
+
+    def reinit(self, env=None, policy=None):
+        self._wrapped_sampler.reinit(env=env, policy=policy)
+
+    def sample(self) -> list:
+        full = self._wrapped_sampler.sample()
+        rets = np.array([ro.undiscounted_return() for ro in full])
+        self.full_stats = {"full avg rollout len": float(np.mean([ro.length for ro in full])),
+                           "full avg return": float(rets.mean()), "full median return": float(np.median(rets)),
+                           "full std return": float(rets.std())}
+        return select_cvar(full, self.epsilon, self.gamma)

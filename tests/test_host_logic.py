@@ -260,6 +260,45 @@ def test_step_sequence():
         StepSequence(observations=np.zeros((3, 2)), actions=np.zeros((3, 1)), rewards=[1.0, 2.0, 3.0])
 
 
+def test_cvar_selection_and_sampler_counts():
+    """select_cvar / CVaRSampler (P/sampling/cvar_sampler.py:40-140): worst epsilon-quantile by discounted return; the inner
+    sampler is asked for 1 / epsilon times as much"""
+    from simurlacra_amd.sampling import CVaRSampler, select_cvar
+
+    ros = [StepSequence(observations=np.zeros((3, 1)), actions=np.zeros((2, 1)), rewards=[r, 2 * r]) for r in (5.0, -1.0, 3.0, 0.5, 9.0, -4.0, 2.0, 7.0, 1.0, -2.0)]
+    worst = select_cvar(list(ros), 0.3)
+    assert [ro.undiscounted_return() for ro in worst] == [-12.0, -6.0, -3.0]
+    assert [ro.rewards[0] for ro in select_cvar(list(ros), 0.2, gamma=0.5)] == [-4.0, -2.0]
+    with pytest.raises(vs.ValueErr):
+        select_cvar(list(ros), 0.01)
+
+    class Inner:
+        def __init__(self):
+            self.counts = None
+
+        def set_min_count(self, min_rollouts=None, min_steps=None):
+            self.counts = (min_rollouts, min_steps)
+
+        def reinit(self, env=None, policy=None):
+            self.re = (env, policy)
+
+        def sample(self):
+            return list(ros)
+
+    inner = Inner()
+    cs = CVaRSampler(inner, epsilon=0.2, min_rollouts=4)
+    assert inner.counts == (20, None)
+    cs.set_min_count(min_steps=1000)
+    assert inner.counts == (None, 5000)
+    got = cs.sample()
+    assert len(got) == 2 and got[0].undiscounted_return() == -12.0
+    assert cs.full_stats["full avg return"] == pytest.approx(np.mean([3 * r for r in (5.0, -1.0, 3.0, 0.5, 9.0, -4.0, 2.0, 7.0, 1.0, -2.0)]))
+    cs.reinit(env="e", policy="p")
+    assert inner.re == ("e", "p")
+    with pytest.raises(vs.ValueErr):
+        CVaRSampler(inner, epsilon=0.0, min_rollouts=4)
+
+
 def test_shard_layout():
     from simurlacra_amd.dist import shard
 
