@@ -9,7 +9,7 @@
 //   k_step          vs_step           one step per launch, actions from the caller (policy in the loop)
 //   k_rollout       vs_step_random    k steps per launch, on-device uniform policy, state in registers, optional records
 //   k_rollout_ws    vs_step_random    the same on two cooperating waves per 64 envs (physics | reward + records) through
-//                                     LDS: what runs while there is less than ~1.25 waves of envs per SIMD
+//                                     LDS: what runs up to one 256-env workgroup per compute unit (65 536 envs)
 //   k_*_mixed       vs_mixed_*        several families in one launch (one workgroup = one family)
 //   k_step_jac      vs_step_jac       step + Jacobians by forward-mode dual numbers
 //   k_reset / k_set_params / k_sample_params / k_observe   control path
@@ -1214,6 +1214,7 @@ struct vs_env {
     float* d_pbuf = nullptr;      // DomainRandWrapperBuffer parameter sets
     float* d_ring = nullptr;      // ActDelayWrapper ring (Pipe::ring)
     int rollout_variant = -1;     // vs_set_rollout_variant: -1 automatic, 0 k_rollout, 1 k_rollout_ws
+    int n_cu = 256;               // compute units of the device (256 on MI355X)
     bool auto_reset = false;
     uint64_t ar_seed = 0;
     bool uniform = true;
@@ -1344,7 +1345,7 @@ static void launch_step(vs_handle h, const float* act, long es, long ds) {
 #undef LS
 }
 
-// The wave-specialised kernel pays while k_rollout would leave a SIMD with a single wave (about 64 lanes x 1024 SIMDs),
+// The wave-specialised kernel pays while k_rollout would leave a SIMD with a single wave (up to 256 envs per compute unit),
 // for the families whose step splits into two comparable halves (E::WS_PAYS), and needs constants that do not change
 // inside the launch.  VS_ROLLOUT_VARIANT=plain|ws overrides for every handle (experiments).
 template <class E>
@@ -1358,7 +1359,9 @@ static bool use_ws(vs_handle h) {
     static const char* force = getenv("VS_ROLLOUT_VARIANT");
     if (force && force[0] == 'p') return false;
     if (force && force[0] == 'w') return true;
-    return E::WS_PAYS && h->d.ld <= 81920;  // at 131 072 lanes k_rollout already has two waves per SIMD and wins (87.9 vs 97.4 us)
+    // one 256-env workgroup per CU at most: a CU that gets a second one runs four waves per SIMD and the launch waits for it
+    // (73 728 envs with records: 100 us against k_rollout's 79 us; at 65 536: 55 against 69)
+    return E::WS_PAYS && h->d.ld <= (int64_t)WS_ENVS * h->n_cu;
 }
 
 template <class E>
@@ -1500,6 +1503,10 @@ int vs_create(int env_type, int64_t n_envs, double dt, int64_t max_steps, int de
     if (!h) return fail(nullptr, VS_ERR_HIP, "vs_create: out of host memory");
     h->type = env_type;
     h->device = device_id;
+    {
+        int cu = 0;
+        if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cu > 0) h->n_cu = cu;
+    }
     const EnvInfo& ei = ENV_INFO[env_type];
     Task& T = h->task;
     bool defaults = !cfg || cfg->use_defaults;

@@ -942,9 +942,10 @@ def test_rollout_variant_selection(vs):
     e.set_act_pipeline(delay=0)
     assert e.rollout_variant() == "k_rollout_ws"
     e.close()
-    big = vs.VecSimEnv("qq-su", 131072, **KW["qq-su"])
-    assert big.rollout_variant() == "k_rollout"
-    big.close()
+    for n_big in (65537, 73728, 131072):  # more than one 256-env workgroup per compute unit: the plain kernel wins
+        big = vs.VecSimEnv("qq-su", n_big, **KW["qq-su"])
+        assert big.rollout_variant() == "k_rollout", n_big
+        big.close()
     for name, expect in (("omo", "k_rollout_ws"), ("qbb", "k_rollout"), ("qcp-st", "k_rollout"), ("bob", "k_rollout_ws")):
         x = vs.VecSimEnv(name, 4096, **KW[name])
         assert x.rollout_variant() == expect, name
