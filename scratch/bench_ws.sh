@@ -1,11 +1,7 @@
 #!/bin/bash
-for rec in 1 0; do
-  VS_ROLLOUT_VARIANT=plain python bench.py --no-cpu-baseline --record $rec --steps 100 --warmup 10 2>/dev/null | python -c "
+# the two fused kernels on the headline configuration, records on / off
+for rec in 1 0; do for var in plain ws; do
+  VS_ROLLOUT_VARIANT=$var python bench.py --no-cpu-baseline --record $rec --steps 100 --warmup 10 2>/dev/null | python -c "
 import sys, json
-d = json.loads(sys.stdin.read()); print('plain    rec $rec | %.3e | kernel %.4f ms' % (d['value'], d['roofline']['kernel_ms']))"
-  for r in 1 2 4; do
-  VS_ROLLOUT_VARIANT=ws python bench.py --no-cpu-baseline --record $rec --steps 100 --warmup 10 2>/dev/null | python -c "
-import sys, json
-d = json.loads(sys.stdin.read()); print('ws R=$r   rec $rec | %.3e | kernel %.4f ms' % (d['value'], d['roofline']['kernel_ms']))"
-  done
-done
+d = json.loads(sys.stdin.read()); print('%-5s rec $rec | %.3e | kernel %.4f ms | %s' % ('$var', d['value'], d['roofline']['kernel_ms'], d['roofline']['kernel']))"
+done; done
