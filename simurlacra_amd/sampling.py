@@ -178,10 +178,14 @@ def rollout(env, policy, eval: bool = False, max_steps: Optional[int] = None, re
 
 
 class ParallelRolloutSampler:
-    """Drop-in for P/sampling/parallel_rollout_sampler.py:182-323 with the rollouts batched on the GPU."""
+    """Drop-in for P/sampling/parallel_rollout_sampler.py:182-323 with the rollouts batched on the GPU.
+
+    Every rollout of a sample() call is a lane of one handle, `batch_lanes` at a time (default 65 536: one full wave of
+    envs per SIMD; the record buffer of such a batch is T x F x 65 536 floats, 8.4 GB for 4 000-step QQube rollouts -- sized
+    for a 288 GB device; pass a smaller value on less).  `num_workers` is accepted and ignored."""
 
     def __init__(self, env, policy, num_workers: int = 1, *, min_rollouts: int = None, min_steps: int = None,
-                 show_progress_bar: bool = False, seed=NO_SEED, batch_lanes: int = 4096, chunk: int = 128):
+                 show_progress_bar: bool = False, seed=NO_SEED, batch_lanes: int = 65536, chunk: int = 128):
         if min_rollouts is None and min_steps is None:
             raise ValueErr(msg="At least one of min_rollouts and min_steps must be given")  # SamplerBase
         self.min_rollouts, self.min_steps = min_rollouts, min_steps
