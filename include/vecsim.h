@@ -156,7 +156,9 @@ int vs_set_dt(vs_handle h, double dt);
  * ordered with the legacy default stream (torch's default "current stream"), so default-stream work may read the
  * handle's buffers (vs_get) after a launch without further synchronisation.  A caller that runs on another,
  * non-blocking stream (a torch side stream, a hipGraph capture stream) passes that hipStream_t here and the handle
- * launches on it; NULL restores the own stream. */
+ * launches on it; NULL restores the own stream.  For a loop that alternates the caller's default-stream work with vs_step,
+ * pass hipStreamLegacy ((hipStream_t)1): on the very same stream there is no hand-over to pay for (the implicit
+ * synchronisation between the legacy stream and a blocking stream costs ~25 us per step). */
 int vs_set_stream(vs_handle h, void* hip_stream);
 int vs_sync(vs_handle h);
 int64_t vs_n_envs(vs_handle h);

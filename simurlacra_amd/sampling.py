@@ -263,10 +263,9 @@ class ParallelRolloutSampler:
 
         n = len(work)
         v = self._vec_for(n)
-        # the library's kernels and the torch ops that read its buffers must be ordered: on torch's legacy default stream
-        # (pointer 0) the handle's own blocking stream is ordered with it implicitly, any other current stream is handed
-        # to the handle
-        v.use_stream(torch.cuda.current_stream(v.device).cuda_stream or None)
+        # the library's kernels and the torch ops that read its buffers must be ordered: the handle launches on torch's
+        # current stream for the duration of the batch (pointer 0 = the legacy default stream)
+        v.use_stream(torch.cuda.current_stream(v.device).cuda_stream)
         try:
             return self._run_batch_on_stream(v, work, first_index, eval)
         finally:
