@@ -93,6 +93,15 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch's ROCm wheels bundle their own libamdhip64 / libhsa-runtime64 under the SAME sonames as the system ROCm that
+    # libvecsim.so was linked against.  Whichever is loaded first serves both: with torch first, libvecsim shares torch's
+    # runtime (one runtime in the process: device pointers, streams and events are interchangeable); the other way round
+    # torch would be handed the system runtime it was not built for and reports "No HIP GPUs are available".
+    # A plain C host never loads torch and uses the system runtime.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     if not os.path.exists(LIB_PATH):
         raise VecSimLibraryError(
             f"{LIB_PATH} is missing. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -97,6 +97,7 @@ class VecSimPyEnv(SimEnv):
             v = VecSimEnv(self.name, self._num_envs, self._dt, self._max_steps, task_args=self._task_args or None,
                           device=self._device, **self._flags)
             v.set_params_uniform(self._domain_param)
+            v.use_stream(0)  # an env object is stepped from host code next to torch's default stream: launch on it
             self._vec = v
         return self._vec
 

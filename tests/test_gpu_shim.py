@@ -404,3 +404,21 @@ def test_cvar_sampler_over_gpu_rollouts(vs):
     assert len(ros) == 64
     rets = [r.undiscounted_return() for r in ros]
     assert rets == sorted(rets) and np.mean(rets) < cs.full_stats["full avg return"]
+
+
+def test_package_before_torch_in_a_fresh_process(vs):
+    """`import simurlacra_amd` and a first rollout BEFORE torch is imported by the user: the package loads torch's bundled
+    HIP runtime first itself (simurlacra_amd/_lib.py), so both orders work (with libvecsim's runtime loaded first torch
+    used to report 'No HIP GPUs are available')"""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import numpy as np, simurlacra_amd as vs\n"
+            "env = vs.QQubeSwingUpSim(dt=0.004, max_steps=50)\n"
+            "obs = env.reset(); obs, rew, done, _ = env.step(np.array([0.5]))\n"
+            "import torch\n"
+            "print('ok', obs.shape, float(torch.ones(4, device='cuda').sum()))\n") % root
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ok (6,) 4.0" in out.stdout, out.stdout + out.stderr
