@@ -64,9 +64,15 @@ enum vs_buffer {
     VS_EP_LENGTHS = 11,/* i32 [ep_cap] completed-episode lengths */
     VS_EP_ENVIDX = 12, /* i32 [ep_cap] env index of each completed episode */
     VS_EP_COUNT = 13,  /* u32 [1]      number of episodes appended since vs_clear_episodes */
-    VS_TRAJ_REC = 14,  /* f32 [T][F * ld], F = O + A + 1: the records of vs_step_random(record=1), one per env and step:
-                        * [obs BEFORE the step (O) | raw (unclipped) action of the policy (A) | reward].  Row t holds the
-                        * F floats of every env split into planes of 4, 2 and 1 floats per env (F = 4 nq + 2 h2 + h1):
+    VS_TRAJ_REC = 14,  /* f32 [T][F * ld]: the records of a recording vs_step_random, one per env and step.
+                        * record mode 1 (default), F = O + A + 1:
+                        *   [obs BEFORE the step (O) | raw (unclipped) action of the policy (A) | reward]
+                        * record mode 2 (vs_set_record_mode), F = O + A + 1 + S + A + H: everything rollout() keeps per step
+                        * (P/sampling/rollout.py:237-258):
+                        *   [... | state BEFORE the step (S) | applied action env.limit_act(act) (A) | hidden state BEFORE
+                        *    the step (H; qcp: th_ddot)]
+                        * Row t holds the F floats of every env split into planes of 4, 2 and 1 floats per env
+                        * (F = 4 nq + 2 h2 + h1):
                         *   plane q < nq : f32 [ld][4] at float offset 4 ld q          <- record[4q .. 4q+3]
                         *   2-wide plane : f32 [ld][2] at 4 ld nq (if h2)              <- record[4nq], record[4nq+1]
                         *   1-wide plane : f32 [ld]    at (4 nq + 2 h2) ld (if h1)     <- record[F-1]
@@ -74,7 +80,9 @@ enum vs_buffer {
                         * (vs_traj_layout reports nq, h2, h1). */
     VS_TRAJ_RESERVED_15 = 15,
     VS_TRAJ_RESERVED_16 = 16,
-    VS_TRAJ_DONE = 17, /* u8  [T][ld] */
+    VS_TRAJ_DONE = 17, /* u32 [ceil(T / 32)][ld]: done flag of recorded step t of env i = bit (t % 32) of word [t / 32][i].
+                        * A lane keeps the running word in a register and a wave stores it once per 32 steps with one
+                        * coalesced dword store (a byte per env and step was a 64-B partial-line store per wave and step) */
     VS_FAILED = 18,    /* u8  [ld]     Task.has_failed(state) of the last step   P/tasks/base.py:159-167 */
     VS_EPSTAT_COUNT = 19,  /* u32 [ld]  completed episodes per env since vs_clear_episodes */
     VS_EPSTAT_RETSUM = 20, /* f32 [ld]  sum of their undiscounted returns */
@@ -91,6 +99,8 @@ enum vs_buffer {
 #define VS_FLAG_ACT_NORM 4        /* ActNormWrapper fused into the step: incoming actions live in [-1, 1] and are mapped to
                                      lb + (a + 1) (ub - lb) / 2 before anything else sees them
                                      (P/environment_wrappers/action_normalization.py:66-75) */
+#define VS_FLAG_FREEZE_DONE 8     /* vs_set_freeze_done: vs_step leaves lanes alone whose done flag is set (rollout() stops at
+                                     done, P/sampling/rollout.py:185); off by default -- env.step() after done keeps stepping */
 
 /* Task / ctor configuration. Zero-initialise and set `use_defaults = 1` to get the reference defaults
  * (_create_task of each env).  Q and R are diagonal (all reference defaults are). */
@@ -136,8 +146,8 @@ const char* vs_env_name(int env_type);
 const char* vs_param_name(int env_type, int i);
 /* nominal domain parameters (get_nominal_domain_param; qcp honours VS_FLAG_LONG_POLE); out has P floats */
 int vs_nominal_params(int env_type, int flags, float* out);
-/* plane decomposition of a VS_TRAJ_REC row (see vs_buffer): F = O + A + 1 = 4 * nq + 2 * h2 + h1 */
-int vs_traj_layout(int env_type, int* F, int* nq, int* h2, int* h1);
+/* plane decomposition of a VS_TRAJ_REC row in record mode 1 or 2 (see vs_buffer): F = 4 * nq + 2 * h2 + h1 */
+int vs_traj_layout(int env_type, int record_mode, int* F, int* nq, int* h2, int* h1);
 /* library / ABI version */
 int vs_version(void);
 
@@ -237,12 +247,23 @@ int vs_step_random(vs_handle h, uint64_t seed, int k_steps, int record);
 /* The action stream of vs_step_random is Philox(seed; global env index, absolute step index); the handle counts the
  * steps it has taken.  vs_seek_random repositions that counter (0 = start of a fresh batch of rollouts). */
 int vs_seek_random(vs_handle h, uint64_t step_index);
+/* rows of the VS_TRAJ_* buffers (grow-only; a larger capacity replaces and frees the previous buffers) */
 int vs_set_traj_capacity(vs_handle h, int t_max);
+/* what a recording vs_step_random writes per step: 1 = [obs | act | rew] (default), 2 = + [state | act_app | hidden], the
+ * fields rollout() returns in its StepSequence (rollout.py:305-325).  Changing the mode drops the record buffers: set
+ * the capacity again afterwards. */
+int vs_set_record_mode(vs_handle h, int mode);
+int vs_record_mode(vs_handle h);
+/* rollout() stops stepping an env at done (rollout.py:185).  With freeze on (and auto-reset off) vs_step skips the lanes
+ * whose VS_DONE flag is set: state, observation, step counter and flags stay, VS_REW reads 0, and whatever action such a
+ * lane is fed cannot raise its NaN flag.  Off (default): env.step() after done keeps stepping, as in the reference. */
+int vs_set_freeze_done(vs_handle h, int on);
 /* which kernel the next vs_step_random launches for this handle's configuration: 0 = k_rollout (one wave per 64 envs),
- * 1 = k_rollout_ws (a physics wave and a reward/record wave per 64 envs; chosen while the plain kernel would leave the
- * SIMDs with a single wave).  Results are bit-identical. */
+ * 1 = k_rollout_ws in 256-env workgroups, 2 = k_rollout_ws in 64-env workgroups (a physics wave and a reward/record wave
+ * per 64 envs; chosen while the plain kernel would leave the SIMDs with a single wave, the small workgroups while the
+ * batch cannot give every compute unit a large one).  Results are bit-identical. */
 int vs_rollout_variant(vs_handle h);
-/* pin the choice: -1 automatic (default), 0 k_rollout, 1 k_rollout_ws where the configuration allows it (no wrapper
+/* pin the choice: -1 automatic (default), 0 k_rollout, 1 / 2 k_rollout_ws where the configuration allows it (no wrapper
  * pipeline, no state-and-time dependent final reward; a live randomizer / parameter buffer only for the families with
  * fixed action bounds and an unscaled reward: qq-*, qcp-su), else k_rollout */
 int vs_set_rollout_variant(vs_handle h, int variant);
@@ -281,10 +302,12 @@ int64_t vs_error_count(vs_handle h);
 /* ---- measurement ---- */
 
 /* average device time [ms] of the step kernel over `iters` launches, measured with hipEvents on the handle's stream
- * (mode 0: vs_step with the given device actions, mode 1: vs_step_random(k_steps, record)) */
+ * (mode 0: vs_step with the given device actions, mode 1: vs_step_random(k_steps, record); recording launches rotate
+ * through the record buffer in k_steps-row slots, so a capacity beyond the 256 MiB Infinity Cache makes it an HBM stream) */
 int vs_time_step_kernel(vs_handle h, int mode, const float* actions, int64_t env_stride, int64_t dim_stride,
                         int k_steps, int record, int iters, float* avg_ms);
-/* streaming copy kernel (float4) over `bytes` of device memory: achieved GB/s (in-repo HBM reference point) */
+/* streaming copy kernel (float4, 4 independent 16-B accesses per thread, non-temporal, one-shot grid, own stream) over
+ * `bytes` of device memory: achieved GB/s read + write (in-repo HBM reference point) */
 int vs_membw_probe(int device_id, int64_t bytes, int iters, float* gbps);
 /* the same for a pure write stream (float4 stores): the ceiling of the record stream of vs_step_random */
 int vs_memwrite_probe(int device_id, int64_t bytes, int iters, float* gbps);

@@ -10,7 +10,8 @@ ENV_TYPES = {"omo": 0, "bob": 1, "qq-su": 2, "qcp-su": 3, "qbb": 4, "qq-st": 5, 
 (VS_STATE, VS_OBS, VS_REW, VS_DONE, VS_HIDDEN, VS_STEPCOUNT, VS_ERRFLAG, VS_RETURNS, VS_PARAMS, VS_CONSTS,
  VS_EP_RETURNS, VS_EP_LENGTHS, VS_EP_ENVIDX, VS_EP_COUNT, VS_TRAJ_REC, _VS_RESERVED_15, _VS_RESERVED_16, VS_TRAJ_DONE,
  VS_FAILED, VS_EPSTAT_COUNT, VS_EPSTAT_RETSUM, VS_EPSTAT_LENSUM, VS_JAC_STATE, VS_JAC_REW, VS_JAC_OBS) = range(25)
-VS_FLAG_SIMPLE_DYNAMICS, VS_FLAG_LONG_POLE, VS_FLAG_ACT_NORM = 1, 2, 4
+VS_FLAG_SIMPLE_DYNAMICS, VS_FLAG_LONG_POLE, VS_FLAG_ACT_NORM, VS_FLAG_FREEZE_DONE = 1, 2, 4, 8
+RV_PLAIN, RV_WS256, RV_WS64 = 0, 1, 2  # vs_rollout_variant
 VS_DP_NORMAL, VS_DP_UNIFORM, VS_DP_BERNOULLI = 0, 1, 2
 VS_MAX_ACT_DELAY = 64
 
@@ -29,7 +30,7 @@ class DpSpec(C.Structure):
 _P = C.c_void_p
 _SIGNATURES = {
     "vs_version": (C.c_int, []),
-    "vs_traj_layout": (C.c_int, [C.c_int] + [C.POINTER(C.c_int)] * 4),
+    "vs_traj_layout": (C.c_int, [C.c_int, C.c_int] + [C.POINTER(C.c_int)] * 4),
     "vs_env_dims": (C.c_int, [C.c_int] + [C.POINTER(C.c_int)] * 7),
     "vs_env_name": (C.c_char_p, [C.c_int]),
     "vs_param_name": (C.c_char_p, [C.c_int, C.c_int]),
@@ -63,6 +64,9 @@ _SIGNATURES = {
     "vs_set_rollout_variant": (C.c_int, [_P, C.c_int]),
     "vs_set_traj_capacity": (C.c_int, [_P, C.c_int]),
     "vs_set_traj_offset": (C.c_int, [_P, C.c_int]),
+    "vs_set_record_mode": (C.c_int, [_P, C.c_int]),
+    "vs_record_mode": (C.c_int, [_P]),
+    "vs_set_freeze_done": (C.c_int, [_P, C.c_int]),
     "vs_set_episode_log": (C.c_int, [_P, C.c_int]),
     "vs_clear_episodes": (C.c_int, [_P]),
     "vs_mixed_create": (C.c_int, [C.POINTER(_P), C.c_int, C.POINTER(_P)]),

@@ -227,7 +227,20 @@ struct EnvDefaults {
     }
     // DummyPolicy: act_space.sample_uniform() (P/policies/feed_forward/dummy.py:77-84)
     __device__ static float sample_action(const float*, float lo, float hi, float u01, int) { return lo + (hi - lo) * u01; }
+    // Trig shared between observe() and the dynamics.  A family whose observation holds sin / cos of an angle the dynamics
+    // need too declares TRIG = 2 and TRIG_AT = the index of that (sin, cos) pair inside the observation:
+    //   observe_p(s, tr)      the pair (what a step from the same state reuses: dynamics(..., tr))
+    //   observe_c(s, tr, o)   the observation from the state and the pair (the rest of observe(): more trig for QQube)
+    // observe(s, o) == observe_p + observe_c, statement for statement.  The wave-specialised rollout kernel keeps
+    // observe_p on its physics wave and hands (s, tr) over; the reward / record wave finishes the observation.
+    static constexpr int TRIG = 0, TRIG_AT = 0;
+    template <class R>
+    __device__ static void observe_p(const R*, R*) {}
 };
+// observe_c of the families whose observation is a copy of the state (TRIG == 0)
+#define VS_OBSERVE_C_IS_OBSERVE \
+    template <class R>          \
+    __device__ static void observe_c(const R* s, const R*, R* o) { observe(s, o); }
 
 // =================================================================================================== OMO
 // OneMassOscillatorSim, P/environments/pysim/one_mass_oscillator.py:49-121
@@ -259,6 +272,7 @@ struct Omo : EnvDefaults<1> {
     }
     template <class R>
     __device__ static void observe(const R* s, R* o) { o[0] = s[0]; o[1] = s[1]; }
+    VS_OBSERVE_C_IS_OBSERVE
     __device__ static void sample_init(const Task&, const float*, Rng& g, float* init) {  // :59-60, box.py:169-178
         init[0] = g.uniform(-0.75f, -0.65f);
         init[1] = g.uniform(-0.1f, 0.1f);
@@ -340,6 +354,7 @@ struct BobT : EnvDefaults<1> {
     __device__ static void observe(const R* s, R* o) {
         for (int j = 0; j < 4; ++j) o[j] = s[j];
     }
+    VS_OBSERVE_C_IS_OBSERVE
     __device__ static void sample_init(const Task&, const float* c, Rng& g, float* init) {  // :60-73, compound.py:84-87
         bool right = (g.next() & 1u) != 0u;  // np.random.randint(2)
         float l2 = c[C_XMAX];
@@ -383,9 +398,9 @@ struct QQT : EnvDefaults<1> {
         for (int j = 0; j < 4; ++j) lo[j] = -hi[j];
     }
     __device__ static void act_bounds(const float*, float* lo, float* hi) { hi[0] = 4.5f; lo[0] = -4.5f; }  // MAX_ACT_QQ
-    // ob: observation of the PRE-step state when the caller has it in registers (fused rollout), else nullptr
+    // tr: (sin, cos)(alpha) of the PRE-step state when the caller has them in registers (fused rollout), else nullptr
     template <class R>
-    __device__ static void dynamics(const Task& T, const float* c, R* s, R*, const R* act, const R* ob) {
+    __device__ static void dynamics(const Task& T, const float* c, R* s, R*, const R* act, const R* tr) {
         // dead zone, _step_dynamics :130-131
         R u = act[0];
         if (c[C_TH_NEG] <= u && u <= c[C_TH_POS]) u = 0.f;
@@ -394,7 +409,7 @@ struct QQT : EnvDefaults<1> {
         //   v' = v + dt a,  p' = p + dt v + dt^2/2 a        (closed form verified against the oracle: max abs diff 0)
         R thd = s[2], ald = s[3];
         R sin_al, cos_al;
-        if (ob) { sin_al = ob[2]; cos_al = ob[3]; }  // observe() already holds sin/cos(alpha) of this state
+        if (tr) { sin_al = tr[0]; cos_al = tr[1]; }  // observe() already holds sin/cos(alpha) of this state
         else sincos_fast(s[1], &sin_al, &cos_al);
         R sin_2al = 2.0f * sin_al * cos_al;
         R a = c[C_C0] + c[C_C1] * sin_al * sin_al;
@@ -419,6 +434,17 @@ struct QQT : EnvDefaults<1> {
     __device__ static void observe(const R* s, R* o) {  // :148-149
         sincos_fast(s[0], &o[0], &o[1]);
         sincos_fast(s[1], &o[2], &o[3]);
+        o[4] = s[2];
+        o[5] = s[3];
+    }
+    static constexpr int TRIG = 2, TRIG_AT = 2;
+    template <class R>
+    __device__ static void observe_p(const R* s, R* tr) { sincos_fast(s[1], &tr[0], &tr[1]); }
+    template <class R>
+    __device__ static void observe_c(const R* s, const R* tr, R* o) {
+        sincos_fast(s[0], &o[0], &o[1]);
+        o[2] = tr[0];
+        o[3] = tr[1];
         o[4] = s[2];
         o[5] = s[3];
     }
@@ -493,10 +519,10 @@ struct QcpT : EnvDefaults<1> {
     __device__ static void act_bounds(const float*, float* lo, float* hi) { hi[0] = 6.0f; lo[0] = -6.0f; }  // MAX_ACT_QCP
     // one evaluation of QCartPoleSim._dynamics (:166-230) on the augmented state y = [x, th, x_dot, th_dot], action u
     template <class R>
-    __device__ static void f_dyn(const Task& T, const float* c, const R* y, R u, R thdd_prev, R* k, R& thdd_out, const R* ob) {
+    __device__ static void f_dyn(const Task& T, const float* c, const R* y, R u, R thdd_prev, R* k, R& thdd_out, const R* tr) {
         R th = y[1], x_dot = y[2], th_dot = y[3];
         R sin_th, cos_th;
-        if (ob) { sin_th = ob[1]; cos_th = ob[2]; }
+        if (tr) { sin_th = tr[0]; cos_th = tr[1]; }
         else sincos_fast(th, &sin_th, &cos_th);
         bool simple = (T.flags & 1) != 0;
         if (!simple && c[C_TH_NEG] <= u && u <= c[C_TH_POS]) u = 0.f;  // dead zone :188-192
@@ -521,12 +547,12 @@ struct QcpT : EnvDefaults<1> {
         thdd_out = th_ddot;
     }
     template <class R>
-    __device__ static void dynamics(const Task& T, const float* c, R* s, R* h, const R* act, const R* ob) {
+    __device__ static void dynamics(const Task& T, const float* c, R* s, R* h, const R* act, const R* tr) {
         // rk4 (:591-655) over [x, th, x_dot, th_dot, u]; u has zero derivative; th_ddot chained through the stages.
         // The four stage vectors live in VGPRs (16 floats per lane): there is no cross-lane reuse to stage in LDS.
         R u = act[0], dt = T.dt, dt2 = dt / 2.0f;
         R k1[4], k2[4], k3[4], k4[4], y[4], a1, a2, a3, a4;
-        f_dyn(T, c, s, u, h[0], k1, a1, ob);
+        f_dyn(T, c, s, u, h[0], k1, a1, tr);
         for (int j = 0; j < 4; ++j) y[j] = s[j] + dt2 * k1[j];
         f_dyn(T, c, y, u, a1, k2, a2, (const R*)nullptr);
         for (int j = 0; j < 4; ++j) y[j] = s[j] + dt2 * k2[j];
@@ -540,6 +566,17 @@ struct QcpT : EnvDefaults<1> {
     __device__ static void observe(const R* s, R* o) {  // :107-108
         o[0] = s[0];
         sincos_fast(s[1], &o[1], &o[2]);
+        o[3] = s[2];
+        o[4] = s[3];
+    }
+    static constexpr int TRIG = 2, TRIG_AT = 1;
+    template <class R>
+    __device__ static void observe_p(const R* s, R* tr) { sincos_fast(s[1], &tr[0], &tr[1]); }
+    template <class R>
+    __device__ static void observe_c(const R* s, const R* tr, R* o) {
+        o[0] = s[0];
+        o[1] = tr[0];
+        o[2] = tr[1];
         o[3] = s[2];
         o[4] = s[3];
     }
@@ -586,9 +623,9 @@ struct Pend : EnvDefaults<1> {
     }
     __device__ static void act_bounds(const float* c, float* lo, float* hi) { hi[0] = c[C_AMAX]; lo[0] = -c[C_AMAX]; }
     template <class R>
-    __device__ static void dynamics(const Task& T, const float* c, R* s, R*, const R* act, const R* ob) {
+    __device__ static void dynamics(const Task& T, const float* c, R* s, R*, const R* act, const R* tr) {
         R sn, cs;
-        if (ob) sn = ob[0];
+        if (tr) sn = tr[0];
         else sincos_fast(s[0], &sn, &cs);
         R th_ddot = (act[0] - c[C_MGL2] * sn - c[C_DAMP] * s[1]) * c[C_INV_J];  // :103-106
         s[1] += th_ddot * T.dt;  // symplectic Euler :109-110
@@ -597,6 +634,15 @@ struct Pend : EnvDefaults<1> {
     template <class R>
     __device__ static void observe(const R* s, R* o) {  // :91-92
         sincos_fast(s[0], &o[0], &o[1]);
+        o[2] = s[1];
+    }
+    static constexpr int TRIG = 2, TRIG_AT = 0;
+    template <class R>
+    __device__ static void observe_p(const R* s, R* tr) { sincos_fast(s[0], &tr[0], &tr[1]); }
+    template <class R>
+    __device__ static void observe_c(const R* s, const R* tr, R* o) {
+        o[0] = tr[0];
+        o[1] = tr[1];
         o[2] = s[1];
     }
     __device__ static void sample_init(const Task& T, const float*, Rng&, float* init) {  // SingularStateSpace :76
@@ -719,6 +765,7 @@ struct Qbb : EnvDefaults<2> {
     __device__ static void observe(const R* s, R* o) {
         for (int j = 0; j < 8; ++j) o[j] = s[j];
     }
+    VS_OBSERVE_C_IS_OBSERVE
     __device__ static void sample_init(const Task&, const float* c, Rng& g, float* init) {  // :108-117, polar.py:108-113
         float l2 = c[C_XMAX];
         float r = g.uniform(0.75f * l2, 0.8f * l2);

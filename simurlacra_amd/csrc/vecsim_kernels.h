@@ -1,0 +1,1419 @@
+// vecsim_kernels.h -- libvecsim: the HIP kernels (gfx950 / CDNA4) and their launchers.
+//
+// One environment per wavefront lane, all per-env data fp32 struct-of-arrays [dim][ld] so that every load/store of a
+// wave is one contiguous 256-B segment.  The step of SimPyEnv (reward -> clip -> dead zone -> integrate -> done ->
+// final reward -> observe, P/environments/pysim/base.py:217-241) is ONE kernel; there is no CPU fallback anywhere:
+// every entry point either runs on the GPU or returns an error.
+//
+// Kernels:
+//   k_step          vs_step           one step per launch, actions from the caller (policy in the loop)
+//   k_rollout       vs_step_random    k steps per launch, on-device uniform policy, state in registers, optional records
+//   k_rollout_ws    vs_step_random    the same on two cooperating waves per 64 envs (physics | reward + records) through
+//                                     LDS: what runs while k_rollout would leave the SIMDs with a single wave
+//   k_*_mixed       vs_mixed_*        several families in one launch (one workgroup = one family)
+//   k_step_jac      vs_step_jac       step + Jacobians by forward-mode dual numbers
+//   k_reset / k_set_params / k_sample_params / k_observe   control path
+// Variants carrying the wrapper pipeline (action noise / delay, observation normalisation / noise) are separate
+// instantiations (template parameter PIPE): the default kernels do not pay for it.
+//
+// Translation units (built in parallel by build.py and linked into ONE libvecsim.so):
+//   vecsim.hip         the C-ABI of include/vecsim.h (host code, non-template kernels)
+//   vecsim_family.hip  compiled once per env family (-DVS_FAMILY=n): the kernels of that family and their launchers
+//   vecsim_mixed.hip   the mixed-batch kernels (every family's body behind one workgroup-uniform switch)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <climits>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <type_traits>
+#include <vector>
+
+#include "../../include/vecsim.h"
+#include "vecsim_envs.h"
+
+namespace vs {
+
+constexpr int BLOCK = 256;
+
+struct DrSpecs {
+    int n;
+    vs_dp_spec s[MAXP];
+};
+
+// The cheap wrappers scripts stack around these envs, fused into the step instead of being Python objects around it:
+// GaussianActNoiseWrapper (P/environment_wrappers/action_noise.py:38-79), ActDelayWrapper (action_delay.py:37-112),
+// ObsNormWrapper (observation_normalization.py:41-126) and GaussianObsNoiseWrapper (observation_noise.py:38-73).
+// Action side, after ActNormWrapper's de-normalisation:  a -> [+ noise] -> delay ring -> [+ noise] -> env.step
+// Observation side:  obs' = obs * scale + shift + std * z   (any stack of norm / noise stages composes to this)
+struct Pipe {
+    int act_on, obs_on;
+    int delay;              // ActDelayWrapper: the action applied at step t is the one commanded at t - delay (0 before)
+    int act_noise, obs_noise;
+    int noise_normed;       // the noise wrapper sits outside ActNormWrapper: its draw is in [-1, 1] units
+    int noise_after_delay;  // the noise wrapper sits inside ActDelayWrapper
+    float a_mean[MAXA], a_std[MAXA];
+    float o_scale[MAXO], o_shift[MAXO], o_std[MAXO];
+    float* ring;            // [delay][A][ld]
+    uint64_t seed;          // noise streams: Philox(seed; env, RNG_*_NOISE, episode index << 32 | step)
+};
+
+// device pointers of one handle, passed to kernels by value
+struct Dev {
+    Pipe pipe;
+    float *state, *hidden, *obs, *rew, *ret, *consts, *params, *consts_uni;
+    uint8_t *done, *failed, *err, *yielded;
+    int* step;
+    uint32_t* ep_idx;   // per-env episode counter: the Philox counter of the NEXT reset of that env
+    // per-env statistics of completed episodes since vs_clear_episodes: plain per-lane accumulators, no atomics
+    uint32_t* es_count;
+    float* es_retsum;
+    int* es_lensum;
+    int log_episodes;   // opt-in: also append (return, length, env) to the global ring with ballot compaction
+    DrSpecs drv;        // the live randomizer BY VALUE: kernel arguments live in the constant address space, so a spec is
+                        // fetched with scalar loads (lgkmcnt).  Behind a pointer it was a vector load per spec, and on
+                        // gfx950 a vector load waits for every older record store (one in-order vmcnt): 1-2 us each
+    uint32_t idx0;      // global index of lane 0: every Philox stream is keyed by (idx0 + lane), so results do not depend
+                        // on how a set of envs is split into handles, batches or GPUs
+    const float* pbuf;  // DomainRandWrapperBuffer: [P][pbuf_n] parameter sets (nullptr: none)
+    int pbuf_n, pbuf_mode;  // number of sets; 0 cyclic, 1 random
+    int dr_n;           // its number of specs, by value: the reset path must not wait on a load to learn there is none
+    float* ep_ret;
+    int *ep_len, *ep_env;
+    unsigned* ep_count;
+    unsigned ep_cap;
+    float* traj_rec;     // packed per-step records, see store_record
+    uint32_t* traj_done; // done flags of the recorded steps, one BIT per env and step: word [t / 32][env], bit t % 32
+    int traj_t0;  // record row offset of the next recording vs_step_random
+    float *jac_s, *jac_r, *jac_o;  // step Jacobians (vs_step_jac), allocated on first use
+    unsigned long long* dbg;       // diagnostic builds only (-DVS_WS_STAMP): per-wave cycle sums, [ld / 64][2 roles][4]
+    int n, ld;
+};
+
+#ifdef VS_WS_STAMP  // diagnostic builds only: where the two waves of k_rollout_ws spend their cycles
+#define VS_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#else
+#define VS_STAMP(var)
+#endif
+
+// ------------------------------------------------------------------------------------------------- wrapper pipeline
+__device__ __forceinline__ void box_muller(uint32_t b0, uint32_t b1, float& z0, float& z1) { Rng::box_muller(b0, b1, z0, z1); }
+
+// a: the action in the env's own units (after ActNormWrapper); step: curr_step of the lane before this step
+template <class E>
+__device__ __forceinline__ void pipe_act(const Dev& d, int i, uint32_t epi, int step, const float* c, float* a) {
+    static_assert(E::A <= MAXA, "action width");
+    const Pipe& p = d.pipe;
+    float nz[E::A];
+#pragma unroll
+    for (int j = 0; j < E::A; ++j) nz[j] = 0.f;
+    if (p.act_noise) {
+        uint4 b = Rng::philox(p.seed, d.idx0 + (uint32_t)i, RNG_ACT_NOISE, ((uint64_t)epi << 32) | (uint32_t)step);
+        float z[2];
+        box_muller(b.x, b.y, z[0], z[1]);
+        float lb[E::A], ub[E::A];
+        E::act_bounds(c, lb, ub);
+#pragma unroll
+        for (int j = 0; j < E::A; ++j)
+            nz[j] = (p.a_mean[j] + p.a_std[j] * z[j]) * (p.noise_normed ? 0.5f * (ub[j] - lb[j]) : 1.0f);
+    }
+    if (!p.noise_after_delay) {
+#pragma unroll
+        for (int j = 0; j < E::A; ++j) a[j] += nz[j];
+    }
+    if (p.delay > 0) {
+        // the queue of the reference starts as `delay` zero actions at reset; a ring slot is only read once the
+        // episode has written it, so nothing has to be cleared at reset
+        int slot = step % p.delay;
+#pragma unroll
+        for (int j = 0; j < E::A; ++j) {
+            float* r = p.ring + ((size_t)slot * E::A + j) * d.ld + i;
+            float prev = step >= p.delay ? *r : 0.f;
+            *r = a[j];
+            a[j] = prev;
+        }
+    }
+    if (p.noise_after_delay) {
+#pragma unroll
+        for (int j = 0; j < E::A; ++j) a[j] += nz[j];
+    }
+}
+
+// step: curr_step of the lane the observation belongs to (0 for the observation reset() returns)
+template <class E>
+__device__ __forceinline__ void pipe_obs(const Dev& d, int i, uint32_t epi, int step, const float* ob, float* out) {
+    static_assert(E::O <= MAXO, "observation width");
+    const Pipe& p = d.pipe;
+    float z[MAXO];
+#pragma unroll
+    for (int j = 0; j < MAXO; ++j) z[j] = 0.f;
+    if (p.obs_noise) {
+        Rng g(p.seed, d.idx0 + (uint32_t)i, RNG_OBS_NOISE, ((uint64_t)epi << 32) | (uint32_t)step);
+#pragma unroll
+        for (int j = 0; j < E::O; j += 2) {
+            uint32_t b0 = g.next(), b1 = g.next();
+            box_muller(b0, b1, z[j], z[j + 1]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < E::O; ++j) out[j] = fmaf(ob[j], p.o_scale[j], p.o_shift[j]) + p.o_std[j] * z[j];
+}
+
+// ---------------------------------------------------------------------------------------------------- reward / step
+// DesStateTask.step_rew / RadiallySymmDesStateTask.step_rew + the three reward functions
+// (P/tasks/desired_state.py:107-110,146-155; P/tasks/reward_functions.py:212-221,237-244,276-282)
+template <class E, class R>
+__device__ __forceinline__ R step_reward(const Task& T, const float* c, const R* s, const R* a_raw) {
+    R cost = 0.f;
+#pragma unroll
+    for (int j = 0; j < E::S; ++j) {
+        R e = T.des[j] - s[j];
+        if (E::RADIAL >= 0) {
+            if (j == E::RADIAL) e = fmod_2pi(e);
+            e = fold_pi(e);  // all dims (Q4)
+        }
+        cost += e * (T.qd[j] * e);
+    }
+    R ca = 0.f;
+#pragma unroll
+    for (int j = 0; j < E::A; ++j) ca += a_raw[j] * (T.rd[j] * a_raw[j]);  // err_a = -act
+    cost += ca;
+    if (E::REW == REW_QUADR) return -cost;
+    if (E::REW == REW_EXP) return exp_neg_fast(-cost);
+    return exp_neg_fast(-c[E::CMAX >= 0 ? E::CMAX : 0] * cost);
+}
+
+// not state_space.contains(s') (Q9, Q10) for a symmetric box: some |s_j| > hi_j  <=>  max_j (|s_j| - hi_j) > 0.
+// One compare at the end instead of one per dimension: every v_cmp feeds a scalar mask and a chain of s_or, and each
+// VALU -> SALU hand-over stalls a lone wave.  The differences are exact (|s| - hi is 0 or at least an ulp of values of order
+// 1..100, never subnormal); NaN dimensions drop out of the max (maxNum), as `NaN > hi` is false.
+template <int S>
+__device__ __forceinline__ bool outside_symmetric_box(const float* sv, const float* hi) {
+    float m = fabsf(sv[0]) - hi[0];
+#pragma unroll
+    for (int j = 1; j < S; ++j) m = fmaxf(m, fabsf(sv[j]) - hi[j]);
+    return m > 0.f;
+}
+
+template <class R>
+struct StepOutT {
+    R rew;
+    bool done, failed, err;
+};
+using StepOut = StepOutT<float>;
+
+// SimPyEnv.step for one lane (P/environments/pysim/base.py:217-241); s, h, step, yielded are updated in place.
+// tr: E::observe_p of the pre-step state if the caller holds it in registers (the trig observe() shares with the dynamics)
+template <class E, class R>
+__device__ __forceinline__ StepOutT<R> step_one(const Task& T, const float* c, R* s, R* h, const R* a_raw, int& step,
+                                                bool& yielded, const R* tr, const Dev* dp = nullptr, int lane = 0,
+                                                uint32_t epi = 0u) {
+    StepOutT<R> o;
+    // ActNormWrapper._process_act (action_normalization.py:66-72), branch-free: a wave-uniform select keeps the step one
+    // basic block for the scheduler
+    R an[E::A];
+    {
+        const bool nrm = (T.flags & VS_FLAG_ACT_NORM) != 0;
+        float lb[E::A], ub[E::A];
+        E::act_bounds(c, lb, ub);
+#pragma unroll
+        for (int j = 0; j < E::A; ++j) {
+            R m = lb[j] + (a_raw[j] + 1.0f) * (ub[j] - lb[j]) * 0.5f;
+            an[j] = vsel(nrm, m, a_raw[j]);
+        }
+        if constexpr (std::is_same<R, float>::value) {
+            if (dp && dp->pipe.act_on) pipe_act<E>(*dp, lane, epi, step, c, an);  // wave-uniform branch
+        }
+        a_raw = an;
+    }
+#ifdef VS_ABLATE_REWARD  // diagnostic builds only (profiling by ablation); never defined in the shipped library
+    o.rew = a_raw[0];
+#else
+    o.rew = step_reward<E, R>(T, c, s, a_raw);  // pre-step state, unclipped action (Q3)
+#endif
+    float alo[E::A], ahi[E::A];
+    R a[E::A];
+    E::act_bounds(c, alo, ahi);
+    o.err = false;
+#pragma unroll
+    for (int j = 0; j < E::A; ++j) o.err |= visnan(a_raw[j]);
+    E::limit_act(c, alo, ahi, a_raw, a);  // Env.limit_act -> act_space.project_to
+#ifdef VS_ABLATE_DYNAMICS
+    s[0] += a[0] * 1e-6f;
+#else
+    E::dynamics(T, c, s, h, a, tr);
+#endif
+    step += 1;
+    float slo[E::S], shi[E::S];
+    E::state_bounds(c, slo, shi);
+    o.failed = false;
+    float svv[E::S];
+#pragma unroll
+    for (int j = 0; j < E::S; ++j) {
+        svv[j] = val(s[j]);
+        o.err |= isnan(svv[j]);
+        // not state_space.contains(s') (Q9, Q10): s < lo or s > hi, NaN compares false as in NumPy
+        if (!E::SYMMETRIC_BOX) o.failed |= (svv[j] < slo[j]) | (svv[j] > shi[j]);
+    }
+    if (E::SYMMETRIC_BOX) o.failed = outside_symmetric_box<E::S>(svv, shi);
+    o.done = o.failed | (step >= T.max_steps);
+    if (E::FINAL != FINAL_NONE) {
+        // FinalRewTask.compute_final_rew, paid once per episode (P/tasks/final_reward.py:130-135)
+        if (o.done && !yielded) {
+            if (o.failed) {
+                if (E::FINAL == FINAL_CONST_MALUS) {
+                    o.rew += -1000.0f;  // always_negative, factor 1e3 (:165-174)  [R += float]
+                } else {
+                    // state- and time-dependent (:215-226): -remaining_steps * |step_rew(s', act = 0)|, remaining_steps as
+                    // computed before the step (pysim/base.py:219); 0 for max_steps = inf
+                    R zero[E::A];
+#pragma unroll
+                    for (int j = 0; j < E::A; ++j) zero[j] = 0.f;
+                    float remaining = T.max_steps == INT_MAX ? 0.f : (float)(T.max_steps - step);
+                    o.rew += -1.0f * remaining * vabs(step_reward<E, R>(T, c, s, zero));
+                }
+            }
+            yielded = true;
+        }
+    }
+    return o;
+}
+
+template <class E, bool UNI>
+__device__ __forceinline__ void load_consts(const Dev& d, int i, float* c, int first, int last) {
+#pragma unroll
+    for (int k = 0; k < E::K; ++k)
+        if (k >= first && k < last) c[k] = UNI ? d.consts_uni[k] : d.consts[(size_t)k * d.ld + i];
+}
+
+// DomainRandomizer.randomize for one lane (domain_parameter.py:104-132): draw -> clamp; writes the raw params
+template <class E>
+__device__ __forceinline__ void draw_params(const DrSpecs* dr, Rng& g, float* p) {
+    int n = dr->n;
+    for (int q = 0; q < n; ++q) {
+        const vs_dp_spec sp = dr->s[q];
+        float v;
+        if (sp.kind == VS_DP_NORMAL) v = sp.mean + sp.spread * g.normal();
+        else if (sp.kind == VS_DP_UNIFORM) v = g.uniform(sp.mean - sp.spread, sp.mean + sp.spread);
+        else v = g.u01() < sp.aux ? sp.spread : sp.mean;  // Bernoulli(prob_1): val_1 with probability prob_1, else val_0
+        v = fminf(fmaxf(v, sp.clip_lo), sp.clip_up);
+        if (sp.roundint) v = rintf(v);  // torch.round: half to even
+#pragma unroll
+        for (int k = 0; k < E::P; ++k)
+            if (k == sp.param_index) p[k] = v;
+    }
+}
+
+template <class E>
+__device__ __forceinline__ void redraw_lane_params(const Task& T, const Dev& d, const DrSpecs* dr, int i, uint64_t seed,
+                                                   uint64_t epi, float* c) {
+    float p[E::P];
+#pragma unroll
+    for (int k = 0; k < E::P; ++k) p[k] = d.params[(size_t)k * d.ld + i];
+    Rng gp(seed, d.idx0 + (uint32_t)i, RNG_PARAM, epi);
+    draw_params<E>(dr, gp, p);
+    E::calc_consts(T, p, c);
+#pragma unroll
+    for (int k = 0; k < E::P; ++k) d.params[(size_t)k * d.ld + i] = p[k];
+#pragma unroll
+    for (int k = 0; k < E::K; ++k) d.consts[(size_t)k * d.ld + i] = c[k];
+}
+
+// SimPyEnv.reset for one lane with a sampled init state (P/environments/pysim/base.py:166-203), incl. the
+// DomainRandWrapperLive redraw (environment_wrappers/domain_randomization.py:141-148) when a randomizer is set.
+// Every draw is a pure function of (seed, env index, episode index epi): independent of launch geometry, of how the
+// steps are chunked into launches and of hipGraph replay.
+template <class E>
+__device__ __forceinline__ void reset_lane_sampled(const Task& T, const Dev& d, bool with_dr, int i, uint64_t seed,
+                                                   uint64_t epi, float* c, float* s, float* h) {
+    if (with_dr && d.dr_n > 0) redraw_lane_params<E>(T, d, &d.drv, i, seed, epi, c);
+    if (with_dr && d.pbuf_n > 0) {
+        // DomainRandWrapperBuffer.reset (domain_randomization.py:236-251): next set of the ring, or a random one
+        uint32_t k;
+        if (d.pbuf_mode == 0) k = (uint32_t)(((uint64_t)d.idx0 + (uint64_t)i + epi) % (uint64_t)d.pbuf_n);
+        else k = Rng::philox(seed, d.idx0 + (uint32_t)i, RNG_PARAM, epi).x % (uint32_t)d.pbuf_n;
+        float p[E::P];
+#pragma unroll
+        for (int q = 0; q < E::P; ++q) p[q] = d.pbuf[(size_t)q * d.pbuf_n + k];
+        E::calc_consts(T, p, c);
+#pragma unroll
+        for (int q = 0; q < E::P; ++q) d.params[(size_t)q * d.ld + i] = p[q];
+#pragma unroll
+        for (int q = 0; q < E::K; ++q) d.consts[(size_t)q * d.ld + i] = c[q];
+    }
+    Rng g(seed, d.idx0 + (uint32_t)i, RNG_INIT, epi);
+    float init[E::I];
+    E::sample_init(T, c, g, init);
+    E::state_from_init(init, s);
+    E::init_hidden(T, c, nullptr, s, h, false);
+}
+
+// completed-episode append with a wavefront ballot: one atomic per wave, lanes ranked by popcount of the lower mask
+__device__ __forceinline__ void append_episode(const Dev& d, bool fin, int i, float ret, int len) {
+    unsigned long long m = __builtin_amdgcn_ballot_w64(fin);
+    if (m == 0ull) return;
+    unsigned lane = __lane_id();
+    int leader = __ffsll((long long)m) - 1;
+    unsigned base = 0;
+    if ((int)lane == leader) base = atomicAdd(d.ep_count, (unsigned)__popcll(m));
+    base = __shfl(base, leader);
+    if (fin) {
+        unsigned slot = (base + (unsigned)__popcll(m & ((1ull << lane) - 1ull))) % d.ep_cap;
+        d.ep_ret[slot] = ret;
+        d.ep_len[slot] = len;
+        d.ep_env[slot] = i;
+    }
+}
+
+// per-lane bookkeeping of finished episodes, kept in registers by the kernels
+struct EpStat {
+    uint32_t epi;    // Dev::ep_idx
+    uint32_t count;  // Dev::es_count
+    float retsum;    // Dev::es_retsum
+    int lensum;      // Dev::es_lensum
+};
+
+// auto-reset of the lanes of a wave that finished an episode (wave-uniform early out: most waves have none).
+// No memory traffic unless live domain randomisation rewrites the lane's params/constants or the episode log is on.
+template <class E, bool UNI>
+__device__ __forceinline__ void auto_reset(const Task& T, const Dev& d, bool fin, int i, uint64_t seed, float* c,
+                                           float* s, float* h, int& step, float& ret, bool& yielded, EpStat& es) {
+    if (__builtin_amdgcn_ballot_w64(fin) == 0ull) return;
+    if (d.log_episodes) append_episode(d, fin, i, ret, step);
+    if (fin) {
+        es.count += 1u;
+        es.retsum += ret;
+        es.lensum += step;
+        load_consts<E, UNI>(d, i, c, E::KS, E::K);  // reset-only constants
+        reset_lane_sampled<E>(T, d, !UNI, i, seed, (uint64_t)es.epi, c, s, h);
+        es.epi += 1u;
+        step = 0;
+        ret = 0.f;
+        yielded = false;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------- step kernel
+// vs_step: one fused SimPyEnv.step per lane.  AR = auto-reset of finished lanes inside the same launch.
+// No host-side counter enters the kernel: replaying a captured hipGraph of vs_step launches is safe.
+// PIPE: the wrapper pipeline (struct Pipe) is compiled in; the default kernels do not carry it.
+template <class E, bool UNI, bool AR, bool PIPE = false>
+__device__ __forceinline__ void step_body(const Task& T, const Dev& d, const float* __restrict__ act, long env_stride,
+                                          long dim_stride, uint64_t seed, int block) {
+    int i = block * BLOCK + threadIdx.x;
+    if (i >= d.ld) return;
+    const size_t ld = d.ld;
+    float c[E::K], s[E::S], h[E::H > 0 ? E::H : 1], a[E::A];
+    load_consts<E, UNI>(d, i, c, 0, E::KS);
+#pragma unroll
+    for (int j = 0; j < E::S; ++j) s[j] = d.state[j * ld + i];
+#pragma unroll
+    for (int j = 0; j < E::H; ++j) h[j] = d.hidden[j * ld + i];
+    bool valid = i < d.n;
+#pragma unroll
+    for (int j = 0; j < E::A; ++j) a[j] = valid ? act[(size_t)i * env_stride + (size_t)j * dim_stride] : 0.f;
+    int step = d.step[i];
+    bool yielded = E::FINAL != FINAL_NONE ? d.yielded[i] != 0 : false;
+    const bool noisy = PIPE && (d.pipe.act_noise | d.pipe.obs_noise);  // wave-uniform
+    uint32_t epi = noisy ? d.ep_idx[i] : 0u;
+    if (!AR && (T.flags & VS_FLAG_FREEZE_DONE)) {  // wave-uniform flag
+        // rollout() stops at done (rollout.py:185): a lane whose episode has ended keeps its state, observation, step
+        // counter and done flag; its reward reads 0 and nothing it is fed can raise the NaN flag
+        if (d.done[i] != 0) {
+            d.rew[i] = 0.f;
+            return;
+        }
+    }
+
+    StepOut o = step_one<E, float>(T, c, s, h, a, step, yielded, (const float*)nullptr, PIPE ? &d : (const Dev*)nullptr,
+                                   i, epi);
+
+    float ret = d.ret[i] + o.rew;
+    d.rew[i] = o.rew;
+    d.done[i] = o.done;
+    d.failed[i] = o.failed;
+    if (o.err && valid) d.err[i] = 1;  // sticky, write-only
+
+    if (AR) {
+        bool fin = o.done && valid;
+        if (__builtin_amdgcn_ballot_w64(fin) != 0ull) {  // single-step kernel: the per-env counters are touched by finishing lanes only
+            EpStat es{0u, 0u, 0.f, 0};
+            if (fin) es = EpStat{d.ep_idx[i], d.es_count[i], d.es_retsum[i], d.es_lensum[i]};
+            auto_reset<E, UNI>(T, d, fin, i, seed, c, s, h, step, ret, yielded, es);
+            if (fin) {
+                d.ep_idx[i] = es.epi;
+                d.es_count[i] = es.count;
+                d.es_retsum[i] = es.retsum;
+                d.es_lensum[i] = es.lensum;
+            }
+        }
+    }
+
+    float ob[E::O];
+    E::observe(s, ob);
+    if (PIPE && d.pipe.obs_on) {
+        if (AR && noisy) epi = d.ep_idx[i];  // a lane that was just reset shows the first observation of its new episode
+        pipe_obs<E>(d, i, epi, step, ob, ob);
+    }
+#pragma unroll
+    for (int j = 0; j < E::S; ++j) d.state[j * ld + i] = s[j];
+#pragma unroll
+    for (int j = 0; j < E::H; ++j) d.hidden[j * ld + i] = h[j];
+#pragma unroll
+    for (int j = 0; j < E::O; ++j) d.obs[j * ld + i] = ob[j];
+    d.step[i] = step;
+    d.ret[i] = ret;
+    if (E::FINAL != FINAL_NONE) d.yielded[i] = yielded;
+}
+
+template <class E, bool UNI, bool AR, bool PIPE>
+__global__ __launch_bounds__(BLOCK) void k_step(Task T, Dev d, const float* __restrict__ act, long env_stride,
+                                                long dim_stride, uint64_t seed) {
+    step_body<E, UNI, AR, PIPE>(T, d, act, env_stride, dim_stride, seed, (int)blockIdx.x);
+}
+
+// ---------------------------------------------------------------------------------------------------- Jacobian kernel
+// vs_step_jac: vs_step plus d(s', r, obs') / d(s, a) by forward-mode differentiation of the very same step code
+// (Dual<S+A> instead of float, vecsim_dual.h).  What the fork obtains with torch autograd around its re-implemented
+// QCartPole dynamics (P/sampling/rollout.py:836-837, quanser_cartpole.py:233-431) -- here for every family.
+// Input x = (s_0 .. s_{S-1}, a_0 .. a_{A-1}); the hidden state (qcp th_ddot, qbb plate angles) is held constant.
+// Layouts: jac_s [S][S+A][ld], jac_r [S+A][ld], jac_o [O][S+A][ld].  The step values come from the float path and are
+// bit-identical to vs_step.
+template <class E, bool UNI>
+__global__ __launch_bounds__(BLOCK) void k_step_jac(Task T, Dev d, const float* __restrict__ act, long env_stride,
+                                                    long dim_stride) {
+    int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= d.ld) return;
+    constexpr int NI = E::S + E::A;
+    using D = Dual<NI>;
+    const size_t ld = d.ld;
+    float c[E::K];
+    load_consts<E, UNI>(d, i, c, 0, E::KS);
+    D s[E::S], h[E::H > 0 ? E::H : 1], a[E::A], ob[E::O];
+    bool valid = i < d.n;
+#pragma unroll
+    for (int j = 0; j < E::S; ++j) {
+        s[j] = D(d.state[j * ld + i]);
+        s[j].d[j] = 1.f;
+    }
+#pragma unroll
+    for (int j = 0; j < E::H; ++j) h[j] = D(d.hidden[j * ld + i]);
+#pragma unroll
+    for (int j = 0; j < E::A; ++j) {
+        a[j] = D(valid ? act[(size_t)i * env_stride + (size_t)j * dim_stride] : 0.f);
+        a[j].d[E::S + j] = 1.f;
+    }
+    int step = d.step[i];
+    bool yielded = E::FINAL != FINAL_NONE ? d.yielded[i] != 0 : false;
+    // values: the float path, so that they are bit-identical to vs_step (operator-by-operator dual arithmetic cannot
+    // reproduce the FMA contraction of the float expressions); tangents: the dual path on the same inputs
+    float sf[E::S], hf[E::H > 0 ? E::H : 1], af[E::A], obf[E::O];
+#pragma unroll
+    for (int j = 0; j < E::S; ++j) sf[j] = s[j].v;
+#pragma unroll
+    for (int j = 0; j < E::H; ++j) hf[j] = h[j].v;
+#pragma unroll
+    for (int j = 0; j < E::A; ++j) af[j] = a[j].v;
+    int step_d = step;
+    bool yielded_d = yielded;
+    StepOut of = step_one<E, float>(T, c, sf, hf, af, step, yielded, (const float*)nullptr);
+    E::observe(sf, obf);
+    StepOutT<D> o = step_one<E, D>(T, c, s, h, a, step_d, yielded_d, (const D*)nullptr);
+    E::observe(s, ob);
+    d.ret[i] = d.ret[i] + of.rew;
+    d.rew[i] = of.rew;
+    d.done[i] = of.done;
+    d.failed[i] = of.failed;
+    if (of.err && valid) d.err[i] = 1;
+#pragma unroll
+    for (int j = 0; j < E::S; ++j) {
+        d.state[j * ld + i] = sf[j];
+#pragma unroll
+        for (int k = 0; k < NI; ++k) d.jac_s[((size_t)j * NI + k) * ld + i] = s[j].d[k];
+    }
+#pragma unroll
+    for (int j = 0; j < E::H; ++j) d.hidden[j * ld + i] = hf[j];
+#pragma unroll
+    for (int j = 0; j < E::O; ++j) {
+        d.obs[j * ld + i] = obf[j];
+#pragma unroll
+        for (int k = 0; k < NI; ++k) d.jac_o[((size_t)j * NI + k) * ld + i] = ob[j].d[k];
+    }
+#pragma unroll
+    for (int k = 0; k < NI; ++k) d.jac_r[(size_t)k * ld + i] = o.rew.d[k];
+    d.step[i] = step;
+    if (E::FINAL != FINAL_NONE) d.yielded[i] = yielded;
+}
+
+// ---------------------------------------------------------------------------------------------------- step records
+// One env step is recorded as F = O + A + 1 floats  [obs (before the step) | action of the policy | reward].
+// A step's records are stored as planes of 4, 2 or 1 floats per env -- F = 4 * NQ + 2 * H2 + H1 -- each plane [ld][w]:
+// a lane writes its w floats with ONE dwordx4 / dwordx2 / dword store and a wave writes 64 * 4 * w contiguous bytes.
+// QQube: 8 floats = 2 stores instead of 8 (and one address computation instead of eight); no padding for any family.
+// Row t of the buffer starts at float offset t * F * ld; plane q at  4 * ld * q  (then the 2-wide, then the 1-wide plane).
+template <int F>
+struct Planes {
+    static constexpr int NQ = F / 4, H2 = (F % 4) >= 2 ? 1 : 0, H1 = F % 2;
+    // v[0 .. F) of env i into a row of planes with `ld` envs per plane (global memory or LDS)
+    __device__ __forceinline__ static void store(float* __restrict__ row, size_t ld, int i, const float* v) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+            reinterpret_cast<float4*>(row + (size_t)q * 4 * ld)[i] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+        if (H2) reinterpret_cast<float2*>(row + (size_t)NQ * 4 * ld)[i] = make_float2(v[4 * NQ], v[4 * NQ + 1]);
+        if (H1) row[((size_t)NQ * 4 + H2 * 2) * ld + i] = v[F - 1];
+    }
+    __device__ __forceinline__ static void load(const float* row, size_t ld, int i, float* v) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            float4 x = reinterpret_cast<const float4*>(row + (size_t)q * 4 * ld)[i];
+            v[4 * q] = x.x, v[4 * q + 1] = x.y, v[4 * q + 2] = x.z, v[4 * q + 3] = x.w;
+        }
+        if (H2) {
+            float2 x = reinterpret_cast<const float2*>(row + (size_t)NQ * 4 * ld)[i];
+            v[4 * NQ] = x.x, v[4 * NQ + 1] = x.y;
+        }
+        if (H1) v[F - 1] = row[((size_t)NQ * 4 + H2 * 2) * ld + i];
+    }
+};
+// Record modes (vs_set_record_mode): REC = 1 the F1 floats above -- what an on-policy algorithm reads; REC = 2 appends what
+// rollout() also keeps per step (P/sampling/rollout.py:237-258): the state BEFORE the step, the applied action
+// env.limit_act(act) and the hidden state before the step (qcp: th_ddot):
+//   [obs (O) | act (A) | rew | state (S) | act_app (A) | hidden (H)],  F2 = F1 + S + A + H
+template <class E, int REC>
+struct Rec {
+    static constexpr int F = REC == 2 ? E::O + E::A + 1 + E::S + E::A + E::H : E::O + E::A + 1;
+};
+// s_pre / a_app / h_pre are read for REC == 2 only
+template <class E, int REC>
+__device__ __forceinline__ void store_record(float* __restrict__ row, size_t ld, int i, const float* ob, const float* a,
+                                             float rew, const float* s_pre, const float* a_app, const float* h_pre) {
+    constexpr int F = Rec<E, REC>::F;
+    float v[F];
+#pragma unroll
+    for (int j = 0; j < E::O; ++j) v[j] = ob[j];
+#pragma unroll
+    for (int j = 0; j < E::A; ++j) v[E::O + j] = a[j];
+    v[E::O + E::A] = rew;
+    if (REC == 2) {
+        constexpr int B = E::O + E::A + 1;
+#pragma unroll
+        for (int j = 0; j < E::S; ++j) v[B + j] = s_pre[j];
+#pragma unroll
+        for (int j = 0; j < E::A; ++j) v[B + E::S + j] = a_app[j];
+#pragma unroll
+        for (int j = 0; j < E::H; ++j) v[B + E::S + E::A + j] = h_pre[j];
+    }
+    Planes<F>::store(row, ld, i, v);
+}
+
+// done flags of the recorded steps: one bit per env and step, 32 steps to a word, words [t / 32][ld] -- a lane keeps the
+// word of the running 32-step window in a register and a wave stores it with ONE coalesced dword store per 32 steps
+// (a byte per env and step was a 64-B partial-line store per wave and step next to the two 1-KB record stores).
+// Row offsets (vs_set_traj_offset) need not be multiples of 32: the first word is completed, not overwritten.
+struct DoneBits {
+    uint32_t w;
+    __device__ __forceinline__ void begin(const Dev& d, int i, size_t row0) {
+        const unsigned b = (unsigned)(row0 & 31u);  // wave-uniform
+        w = b ? d.traj_done[(row0 >> 5) * (size_t)d.ld + i] & ((1u << b) - 1u) : 0u;
+    }
+    // row = absolute record row of this step; last = it is the last recorded step of the launch (both wave-uniform)
+    __device__ __forceinline__ void put(const Dev& d, int i, size_t row, bool done, bool last) {
+        const unsigned b = (unsigned)(row & 31u);
+        w |= (done ? 1u : 0u) << b;
+        if (b == 31u || last) {
+            d.traj_done[(row >> 5) * (size_t)d.ld + i] = w;
+            w = 0u;
+        }
+    }
+};
+
+// env.limit_act(act) of the OUTERMOST env, what rollout() records as the applied action (rollout.py:244; Env.limit_act
+// P/environments/base.py:215-222): the projection onto the act space the policy sees -- [-1, 1] under ActNormWrapper
+template <class E>
+__device__ __forceinline__ void applied_action(const Task& T, const float* c, const float* alo, const float* ahi,
+                                               const float* a, float* a_app) {
+    const bool nrm = (T.flags & VS_FLAG_ACT_NORM) != 0;
+    float lo[E::A], hi[E::A];
+#pragma unroll
+    for (int j = 0; j < E::A; ++j) {
+        lo[j] = nrm ? -1.0f : alo[j];
+        hi[j] = nrm ? 1.0f : ahi[j];
+    }
+    E::limit_act(c, lo, hi, a, a_app);
+}
+
+// ---------------------------------------------------------------------------------------------------- rollout kernel
+// vs_step_random: rollout() with DummyPolicy (rollout.py:185-239, dummy.py:77-84) -- k env steps per launch, state,
+// hidden state and constants stay in registers; only the per-step records stream to HBM when REC.
+// Without auto-reset a finished lane freezes (rollout stops at done).
+// Actions: Philox4x32-10 keyed by `seed`, counter (env, RNG_ACT, absolute step / SPB); one block feeds SPB = 4 / A
+// consecutive steps (the block boundary is wave-uniform because it depends on the launch-global step index only).
+template <class E, bool UNI, bool AR, int REC, bool PIPE = false>
+__device__ __forceinline__ void rollout_body(const Task& T, const Dev& d, int k_steps, uint64_t seed, uint64_t reset_seed,
+                                             uint64_t epoch0, int block) {
+    const size_t rec0 = (size_t)d.traj_t0;  // first record row of this launch (vs_set_traj_offset)
+    int i = block * BLOCK + threadIdx.x;
+    if (i >= d.ld) return;
+    const size_t ld = d.ld;
+    bool valid = i < d.n;
+    float c[E::K], s[E::S], h[E::H > 0 ? E::H : 1], a[E::A], ob[E::O];
+    load_consts<E, UNI>(d, i, c, 0, E::KS);
+#pragma unroll
+    for (int j = 0; j < E::S; ++j) s[j] = d.state[j * ld + i];
+#pragma unroll
+    for (int j = 0; j < E::H; ++j) h[j] = d.hidden[j * ld + i];
+    int step = d.step[i];
+    float ret = d.ret[i];
+    bool yielded = E::FINAL != FINAL_NONE ? d.yielded[i] != 0 : false;
+    bool frozen = !AR && d.done[i] != 0;
+    float rew = d.rew[i];
+    bool done = d.done[i] != 0, failed = d.failed[i] != 0;
+    EpStat es{d.ep_idx[i], d.es_count[i], d.es_retsum[i], d.es_lensum[i]};
+    float alo[E::A], ahi[E::A];
+    E::act_bounds(c, alo, ahi);
+    constexpr unsigned SPB = 4 / E::A;
+    uint4 blk = make_uint4(0, 0, 0, 0);
+    DoneBits db;
+    if (REC) {
+        E::observe(s, ob);
+        db.begin(d, i, rec0);
+    }
+    // gfx950 has ONE vmcnt for loads and stores, in issue order.  Drain the prologue loads here (0x0F70 = vmcnt(0) only) so
+    // that the waitcnt pass knows nothing is pending at the loop header: otherwise the conservative `vmcnt(N)` it places
+    // at the first in-loop use of a prologue load makes every later iteration wait for its own record stores to land.
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+
+    for (int t = 0; t < k_steps; ++t) {
+        uint64_t ta = epoch0 + (uint64_t)t;
+        unsigned sub = (unsigned)(ta % SPB);
+#ifdef VS_ABLATE_RNG
+        blk = make_uint4(blk.x + 0x9E3779B9u * (unsigned)i, blk.y + 77u, blk.z + 5u, blk.w + 1u);
+#else
+        if (t == 0 || sub == 0) blk = Rng::philox(seed, d.idx0 + (uint32_t)i, RNG_ACT, ta / SPB);
+#endif
+#pragma unroll
+        for (int j = 0; j < E::A; ++j) {
+            unsigned e = sub * E::A + j;  // wave-uniform element index
+            uint32_t bits = e == 0 ? blk.x : e == 1 ? blk.y : e == 2 ? blk.z : blk.w;
+            bool nrm = (T.flags & VS_FLAG_ACT_NORM) != 0;  // the policy then acts in the wrapper's space [-1, 1]
+            a[j] = E::sample_action(c, nrm ? -1.0f : alo[j], nrm ? 1.0f : ahi[j], Rng::to_u01(bits), j);  // act_space.sample_uniform()
+        }
+        float ow[E::O];  // the observation as recorded: wrapped when the pipeline is on (the raw one stays in `ob`)
+        float s_pre[E::S], h_pre[E::H > 0 ? E::H : 1], a_app[E::A];  // REC == 2: what rollout() keeps besides obs / act / rew
+        if (REC) {
+            if (PIPE && d.pipe.obs_on) {  // wave-uniform
+                pipe_obs<E>(d, i, es.epi, step, ob, ow);
+            } else {
+#pragma unroll
+                for (int j = 0; j < E::O; ++j) ow[j] = ob[j];
+            }
+        }
+        if (REC == 2) {
+#pragma unroll
+            for (int j = 0; j < E::S; ++j) s_pre[j] = s[j];
+#pragma unroll
+            for (int j = 0; j < E::H; ++j) h_pre[j] = h[j];
+            applied_action<E>(T, c, alo, ahi, a, a_app);
+        }
+        if (!frozen) {
+            StepOut o = step_one<E, float>(T, c, s, h, a, step, yielded,
+                                           (REC && E::TRIG > 0) ? (const float*)(ob + E::TRIG_AT) : (const float*)nullptr,
+                                           PIPE ? &d : (const Dev*)nullptr, i, es.epi);
+            rew = o.rew;
+            done = o.done;
+            failed = o.failed;
+            ret += o.rew;
+            if (o.err && valid) d.err[i] = 1;
+        } else {
+            rew = 0.f;
+        }
+        if (REC) {
+            store_record<E, REC>(d.traj_rec + (rec0 + (size_t)t) * Rec<E, REC>::F * ld, ld, i, ow, a, rew, s_pre, a_app, h_pre);
+            db.put(d, i, rec0 + (size_t)t, done, t == k_steps - 1);
+        }
+        bool fin = done && valid && !frozen;
+        if (AR) {
+            auto_reset<E, UNI>(T, d, fin, i, reset_seed, c, s, h, step, ret, yielded, es);
+            if (!UNI) E::act_bounds(c, alo, ahi);  // the action space may depend on redrawn params (omo, bob)
+        } else {
+            if (fin) {  // rollout() ends here for this lane: book the episode once, then freeze
+                es.count += 1u;
+                es.retsum += ret;
+                es.lensum += step;
+            }
+            if (d.log_episodes) append_episode(d, fin, i, ret, step);
+            frozen |= done;
+            // early termination: a wave whose 64 rollouts have all ended has nothing left to do (the ballot is
+            // wave-uniform, so the whole wave leaves the loop together); with records on it keeps writing its frozen rows
+            if (!REC && __builtin_amdgcn_ballot_w64(!frozen) == 0ull) break;
+        }
+#ifdef VS_ABLATE_OBSERVE
+        if (REC) { for (int j = 0; j < E::O; ++j) ob[j] = s[j % E::S]; }
+#else
+        if (REC) E::observe(s, ob);
+#endif
+    }
+    if (!REC) E::observe(s, ob);
+    if (PIPE && d.pipe.obs_on) pipe_obs<E>(d, i, es.epi, step, ob, ob);
+#pragma unroll
+    for (int j = 0; j < E::S; ++j) d.state[j * ld + i] = s[j];
+#pragma unroll
+    for (int j = 0; j < E::H; ++j) d.hidden[j * ld + i] = h[j];
+#pragma unroll
+    for (int j = 0; j < E::O; ++j) d.obs[j * ld + i] = ob[j];
+    d.step[i] = step;
+    d.ret[i] = ret;
+    d.rew[i] = rew;
+    d.done[i] = done;
+    d.failed[i] = failed;
+    if (E::FINAL != FINAL_NONE) d.yielded[i] = yielded;
+    d.ep_idx[i] = es.epi;
+    d.es_count[i] = es.count;
+    d.es_retsum[i] = es.retsum;
+    d.es_lensum[i] = es.lensum;
+}
+
+template <class E, bool UNI, bool AR, int REC, bool PIPE>
+__global__ __launch_bounds__(BLOCK) void k_rollout(Task T, Dev d, int k_steps, uint64_t seed, uint64_t reset_seed,
+                                                   uint64_t epoch0) {
+    rollout_body<E, UNI, AR, REC, PIPE>(T, d, k_steps, seed, reset_seed, epoch0, (int)blockIdx.x);
+}
+
+// ------------------------------------------------------------------------------------ wave-specialised rollout kernel
+// At the size of the headline metric (65 536 envs) k_rollout has exactly one wave per SIMD, and a lone wave issues a VALU
+// instruction only every ~7 cycles while the SIMD takes one every 4 from two or more waves (the same
+// kernel does 2x the envs in 1.2x the time).  This variant gives every SIMD TWO waves without needing more envs: the step
+// of 64 envs is split between a
+//   P wave ("physics"): ActNorm -> clip -> dead zone -> integrate -> bounds / done -> auto-reset, observe() of the new state
+//                       (owns state, hidden state, step counter)
+//   C wave ("critic"):  the policy's action (Philox), reward of (s_t, a_t), final reward, returns / episode statistics,
+//                       the record stores
+// They exchange through LDS in batches of WS_R env steps, double buffered in both directions: in phase b the P wave
+// integrates batch b with the actions C drew in phase b - 1 and leaves (s_t, obs_t, flags_t) per step; C meanwhile works
+// off the messages of batch b - 1 and draws the actions of batch b + 1.  ONE workgroup barrier per phase (LDS-only wait: the
+// C wave never drains its record stores).  A workgroup is 512 threads = 4 P waves + 4 C waves for 256 envs: the hardware
+// places wave w and wave w + 4 of a workgroup on the same SIMD (scratch/ubench/wave_place.hip: 256 of 256 workgroups), so
+// every SIMD holds one P and one C wave with about half of the instruction stream each.
+// The arithmetic is statement for statement that of step_one / rollout_body (bit-identical results, tested against k_step).
+// Not covered here (vs_step_random falls back to k_rollout): live domain randomisation for the families whose C wave reads
+// per-env constants (action bounds, c_max: they change at a reset inside the launch), the wrapper pipeline, the
+// state-and-time dependent final reward (needs s_{t+1} on the C side).
+enum : unsigned { WSF_DONE = 1u, WSF_FAILED = 2u, WSF_FROZEN = 4u, WSF_FIN = 8u };
+
+__device__ __forceinline__ void ws_barrier() {
+#ifdef VS_WS_NOSYNC  // diagnostic builds only (timing without the exchange; results are wrong)
+    return;
+#endif
+    // LDS traffic only: wait for this wave's LDS ops (lgkmcnt(0)), not for its global stores (a __syncthreads() would also
+    // drain vmcnt and stall the C wave on its record stores in every phase)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// NE = envs per workgroup (a workgroup is NE / 64 P waves followed by NE / 64 C waves):
+//   256  512 threads; wave w and w + 4 share a SIMD, so every SIMD of the CU holds one P and one C wave -- the shape for
+//        one workgroup per compute unit (65 536 envs on 256 CUs)
+//    64  128 threads, one wave of each role on SIMDs of their own -- for batches that cannot fill the chip with 256-env
+//        workgroups (4 096 envs are 16 of those, on 16 of 256 CUs, but 64 of these)
+// The message P -> C of one step is  s_t | E::observe_p(s_t) (records only) | h_t (REC == 2) | flags : the C wave finishes
+// the observation (E::observe_c: for QQube the sin / cos of theta, which the dynamics never need) and P keeps only the trig
+// its next step reuses.
+template <class E, bool UNI, bool AR, int REC, int WS_R, int NE>
+__global__ __launch_bounds__(2 * NE) void k_rollout_ws(Task T, Dev d, int k_steps, uint64_t seed, uint64_t reset_seed,
+                                                       uint64_t epoch0) {
+    static_assert(E::FINAL != FINAL_STATE_TIME, "needs the post-step state on the reward side");
+    static_assert(NE == 64 || NE == 128 || NE == 256, "envs per workgroup");
+    constexpr int HM = REC == 2 ? E::H : 0;                      // hidden state travels for the full records only
+    constexpr int M0 = E::S + (REC ? E::TRIG : 0) + HM + 1;      // message of one step
+    constexpr int M = M0 % 4 == 3 ? M0 + 1 : M0;                 // 4k + 3 floats would be three LDS ops for the tail; pad to a quad
+    constexpr int TR0 = E::S, HM0 = E::S + (REC ? E::TRIG : 0);  // offsets inside the message
+    constexpr int NT = E::TRIG > 0 ? E::TRIG : 1, NH = E::H > 0 ? E::H : 1;
+    __shared__ __attribute__((aligned(16))) float l_msg[2][WS_R][M * NE];
+    __shared__ __attribute__((aligned(16))) float l_act[2][WS_R][E::A * NE];
+    const int wave = threadIdx.x >> 6;
+    const bool role_c = wave >= NE / 64;
+    const int le = threadIdx.x & (NE - 1);  // env slot inside the workgroup
+    const int i = blockIdx.x * NE + le;
+    const size_t ld = d.ld;
+    const bool valid = i < d.n;
+    const int nb = (k_steps + WS_R - 1) / WS_R;
+    float c[E::K];
+    load_consts<E, UNI>(d, i, c, 0, E::KS);
+    float alo[E::A], ahi[E::A];
+    E::act_bounds(c, alo, ahi);
+
+    if (!role_c) {
+        // ------------------------------------------------------------------------------------------- P wave
+        float s[E::S], h[NH], tr[NT], ob[E::O];
+#pragma unroll
+        for (int j = 0; j < E::S; ++j) s[j] = d.state[j * ld + i];
+#pragma unroll
+        for (int j = 0; j < E::H; ++j) h[j] = d.hidden[j * ld + i];
+        int step = d.step[i];
+        uint32_t epi = d.ep_idx[i];
+        bool frozen = !AR && d.done[i] != 0;
+        bool done = d.done[i] != 0, failed = d.failed[i] != 0;
+        if (REC) E::observe_p(s, tr);
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        ws_barrier();  // the actions of batch 0 are in l_act[0]
+#ifdef VS_WS_NOP  // diagnostic: the P wave only keeps the barriers
+        for (int b = 0; b < nb; ++b) ws_barrier();
+        if (false)
+#endif
+#ifdef VS_WS_STAMP
+        unsigned long long acc0 = 0, acc1 = 0, acc2 = 0;
+#endif
+        for (int b = 0; b < nb; ++b) {
+            const int nr = min(WS_R, k_steps - b * WS_R);
+            VS_STAMP(st0);
+            // all actions of the batch up front: one LDS round trip per batch instead of one per step on the critical path
+            float a_all[WS_R][E::A];
+#pragma unroll
+            for (int r = 0; r < WS_R; ++r) Planes<E::A>::load(l_act[b & 1][r], NE, le, a_all[r]);
+#ifdef VS_WS_STAMP
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+            VS_STAMP(st1);
+#pragma unroll
+            for (int r = 0; r < WS_R; ++r) {
+                if (r >= nr) break;
+                const float* a = a_all[r];
+                float v[M];
+#pragma unroll
+                for (int j = 0; j < E::S; ++j) v[j] = s[j];
+                if (REC) {
+#pragma unroll
+                    for (int j = 0; j < E::TRIG; ++j) v[TR0 + j] = tr[j];
+                }
+#pragma unroll
+                for (int j = 0; j < HM; ++j) v[HM0 + j] = h[j];
+                bool fin = false;  // (used for the reset on this side)
+                if (!frozen) {
+                    // the P half of step_one: ActNorm -> limit_act -> _step_dynamics -> curr_step += 1 -> is_done
+                    float an[E::A], ac[E::A];
+                    {
+                        const bool nrm = (T.flags & VS_FLAG_ACT_NORM) != 0;
+                        float lb[E::A], ub[E::A];
+                        E::act_bounds(c, lb, ub);
+#pragma unroll
+                        for (int j = 0; j < E::A; ++j) {
+                            float m = lb[j] + (a[j] + 1.0f) * (ub[j] - lb[j]) * 0.5f;
+                            an[j] = vsel(nrm, m, a[j]);
+                        }
+                    }
+                    bool err = false;
+#pragma unroll
+                    for (int j = 0; j < E::A; ++j) err |= visnan(an[j]);
+                    E::limit_act(c, alo, ahi, an, ac);
+                    E::dynamics(T, c, s, h, ac, (REC && E::TRIG > 0) ? (const float*)tr : (const float*)nullptr);
+                    step += 1;
+                    float slo[E::S], shi[E::S];
+                    E::state_bounds(c, slo, shi);
+                    failed = false;
+#pragma unroll
+                    for (int j = 0; j < E::S; ++j) {
+                        err |= isnan(s[j]);
+                        if (!E::SYMMETRIC_BOX) failed |= (s[j] < slo[j]) | (s[j] > shi[j]);
+                    }
+                    if (E::SYMMETRIC_BOX) failed = outside_symmetric_box<E::S>(s, shi);
+                    done = failed | (step >= T.max_steps);
+                    if (err && valid) d.err[i] = 1;
+                    fin = done && valid;
+                }
+                unsigned fl = (done ? WSF_DONE : 0u) | (E::FINAL != FINAL_NONE && failed ? WSF_FAILED : 0u) |
+                              (!AR && frozen ? WSF_FROZEN : 0u);  // fin = done & !frozen & valid is recomputed by C
+                v[M0 - 1] = __uint_as_float(fl);
+                if (M > M0) v[M - 1] = 0.f;
+                Planes<M>::store(l_msg[b & 1][r], NE, le, v);
+                if (AR) {
+                    if (__builtin_amdgcn_ballot_w64(fin) != 0ull) {
+                        if (fin) {
+                            load_consts<E, UNI>(d, i, c, E::KS, E::K);
+                            // live domain randomisation redraws the lane's parameters here: allowed for the families
+                            // whose C wave does not read constants (use_ws)
+                            reset_lane_sampled<E>(T, d, !UNI, i, reset_seed, (uint64_t)epi, c, s, h);
+                            epi += 1u;
+                            step = 0;
+                        }
+                        if (!UNI) E::act_bounds(c, alo, ahi);
+                    }
+                } else {
+                    frozen |= done;
+                }
+                if (REC) E::observe_p(s, tr);
+            }
+            VS_STAMP(st2);
+            ws_barrier();
+#ifdef VS_WS_STAMP
+            VS_STAMP(st3);
+            acc0 += st1 - st0, acc1 += st2 - st1, acc2 += st3 - st2;
+#endif
+        }
+#ifdef VS_WS_STAMP
+        if ((threadIdx.x & 63) == 0 && d.dbg) {
+            unsigned long long* q = d.dbg + ((size_t)(i >> 6) * 2 + 0) * 4;
+            q[0] = acc0, q[1] = acc1, q[2] = acc2, q[3] = (unsigned long long)nb;
+        }
+#endif
+        E::observe(s, ob);
+#pragma unroll
+        for (int j = 0; j < E::S; ++j) d.state[j * ld + i] = s[j];
+#pragma unroll
+        for (int j = 0; j < E::H; ++j) d.hidden[j * ld + i] = h[j];
+#pragma unroll
+        for (int j = 0; j < E::O; ++j) d.obs[j * ld + i] = ob[j];
+        d.step[i] = step;
+        d.ep_idx[i] = epi;
+        d.done[i] = done;
+        d.failed[i] = failed;
+    } else {
+        // ------------------------------------------------------------------------------------------- C wave
+        const size_t rec0 = (size_t)d.traj_t0;
+        float ret = d.ret[i];
+        float rew = d.rew[i];
+        bool yielded = E::FINAL != FINAL_NONE ? d.yielded[i] != 0 : false;
+        EpStat es{0u, d.es_count[i], d.es_retsum[i], d.es_lensum[i]};
+        int len = d.step[i];
+        constexpr unsigned SPB = 4 / E::A;
+        uint4 blk = make_uint4(0, 0, 0, 0);
+        DoneBits db;
+        if (REC) db.begin(d, i, rec0);
+        // the actions of batch bb: act_space.sample_uniform() per step, the very stream of k_rollout
+        auto draw = [&](int bb) {
+            const int nr = min(WS_R, k_steps - bb * WS_R);
+#pragma unroll
+            for (int r = 0; r < WS_R; ++r) {
+                if (r >= nr) break;
+                const int t = bb * WS_R + r;
+                uint64_t ta = epoch0 + (uint64_t)t;
+                unsigned sub = (unsigned)(ta % SPB);
+                if (t == 0 || sub == 0) blk = Rng::philox(seed, d.idx0 + (uint32_t)i, RNG_ACT, ta / SPB);
+                float a[E::A];
+#pragma unroll
+                for (int j = 0; j < E::A; ++j) {
+                    unsigned e = sub * E::A + j;
+                    uint32_t bits = e == 0 ? blk.x : e == 1 ? blk.y : e == 2 ? blk.z : blk.w;
+                    bool nrm = (T.flags & VS_FLAG_ACT_NORM) != 0;
+                    a[j] = E::sample_action(c, nrm ? -1.0f : alo[j], nrm ? 1.0f : ahi[j], Rng::to_u01(bits), j);
+                }
+                Planes<E::A>::store(l_act[bb & 1][r], NE, le, a);
+            }
+        };
+        // reward, returns and records of the steps of batch bb
+        auto work_off = [&](int bb) {
+            const int nr = min(WS_R, k_steps - bb * WS_R);
+#pragma unroll
+            for (int r = 0; r < WS_R; ++r) {
+                if (r >= nr) break;
+                const int t = bb * WS_R + r;
+                float v[M], a[E::A];
+                Planes<M>::load(l_msg[bb & 1][r], NE, le, v);
+                Planes<E::A>::load(l_act[bb & 1][r], NE, le, a);
+                const unsigned fl = __float_as_uint(v[M0 - 1]);
+                const bool was_frozen = !AR ? (fl & WSF_FROZEN) != 0u : false;
+                const bool done = (fl & WSF_DONE) != 0u, failed = (fl & WSF_FAILED) != 0u;
+                const bool fin = done && !was_frozen && valid;
+                if (!was_frozen) {
+                    len += 1;  // curr_step of the running episode, counted on this side too
+                    float an[E::A];
+                    {
+                        const bool nrm = (T.flags & VS_FLAG_ACT_NORM) != 0;
+                        float lb[E::A], ub[E::A];
+                        E::act_bounds(c, lb, ub);
+#pragma unroll
+                        for (int j = 0; j < E::A; ++j) {
+                            float m = lb[j] + (a[j] + 1.0f) * (ub[j] - lb[j]) * 0.5f;
+                            an[j] = vsel(nrm, m, a[j]);
+                        }
+                    }
+                    rew = step_reward<E, float>(T, c, v, an);  // pre-step state, unclipped action (Q3)
+                    if (E::FINAL == FINAL_CONST_MALUS) {  // once per episode (final_reward.py:130-135, 165-174)
+                        if (done && !yielded) {
+                            if (failed) rew += -1000.0f;
+                            yielded = true;
+                        }
+                    }
+                    ret += rew;
+                } else {
+                    rew = 0.f;
+                }
+                if (REC) {
+                    float ob[E::O], a_app[E::A];
+                    E::observe_c(v, v + TR0, ob);  // the rest of observe(s_t)
+                    if (REC == 2) applied_action<E>(T, c, alo, ahi, a, a_app);
+                    store_record<E, REC>(d.traj_rec + (rec0 + (size_t)t) * Rec<E, REC>::F * ld, ld, i, ob, a, rew, v, a_app,
+                                         v + HM0);
+                    db.put(d, i, rec0 + (size_t)t, done, t == k_steps - 1);
+                }
+                if (__builtin_amdgcn_ballot_w64(fin) != 0ull) {
+                    if (d.log_episodes) append_episode(d, fin, i, ret, len);
+                    if (fin) {
+                        es.count += 1u;
+                        es.retsum += ret;
+                        es.lensum += len;
+                        if (AR) {
+                            ret = 0.f;
+                            yielded = false;
+                            len = 0;
+                        }
+                    }
+                }
+            }
+        };
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        draw(0);
+        ws_barrier();
+#ifdef VS_WS_NOC  // diagnostic: the C wave only keeps the barriers
+        for (int b = 0; b < nb; ++b) ws_barrier();
+        if (false)
+#endif
+#ifdef VS_WS_STAMP
+        unsigned long long acc0 = 0, acc1 = 0, acc2 = 0;
+#endif
+        for (int b = 0; b < nb; ++b) {
+            VS_STAMP(st0);
+            if (b >= 1) work_off(b - 1);  // reads l_act[(b - 1) & 1] before draw(b + 1) overwrites the same buffer
+            VS_STAMP(st1);
+            if (b + 1 < nb) draw(b + 1);
+            VS_STAMP(st2);
+            ws_barrier();
+#ifdef VS_WS_STAMP
+            VS_STAMP(st3);
+            acc0 += st1 - st0, acc1 += st2 - st1, acc2 += st3 - st2;
+#endif
+        }
+#ifdef VS_WS_STAMP
+        if ((threadIdx.x & 63) == 0 && d.dbg) {
+            unsigned long long* q = d.dbg + ((size_t)(i >> 6) * 2 + 1) * 4;
+            q[0] = acc0, q[1] = acc1, q[2] = acc2, q[3] = (unsigned long long)nb;
+        }
+#endif
+        work_off(nb - 1);
+        d.ret[i] = ret;
+        d.rew[i] = rew;
+        if (E::FINAL != FINAL_NONE) d.yielded[i] = yielded;
+        d.es_count[i] = es.count;
+        d.es_retsum[i] = es.retsum;
+        d.es_lensum[i] = es.lensum;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------- mixed batches
+// BASELINE config 5: several env families in ONE launch.  Lanes are sorted by type (one segment = one ordinary handle),
+// a workgroup belongs to exactly one segment, so the type switch is uniform per workgroup and every wavefront takes
+// a single branch.  The bodies are the very functions the single-type kernels run: results are bit-identical.
+constexpr int MAX_SEG = 5;
+struct Seg {
+    int type;
+    int block_end;  // exclusive prefix of workgroups
+    Task T;
+    Dev d;
+    const float* act;
+    long env_stride, dim_stride;
+    uint64_t reset_seed, epoch0;
+};
+struct Segs {
+    int n;
+    Seg s[MAX_SEG];
+};
+
+#ifdef VS_TU_MIXED
+#define MIXED_DISPATCH(type, ...)                                 \
+    switch (type) {                                               \
+        case VS_ENV_OMO: { using E = Omo; __VA_ARGS__; } break;     \
+        case VS_ENV_BOB: { using E = Bob; __VA_ARGS__; } break;     \
+        case VS_ENV_QQ_SU: { using E = QQ; __VA_ARGS__; } break;    \
+        case VS_ENV_QCP_SU: { using E = Qcp; __VA_ARGS__; } break;  \
+        case VS_ENV_QBB: { using E = Qbb; __VA_ARGS__; } break;     \
+        case VS_ENV_QQ_ST: { using E = QQSt; __VA_ARGS__; } break;  \
+        case VS_ENV_QCP_ST: { using E = QcpSt; __VA_ARGS__; } break;\
+        case VS_ENV_PEND: { using E = Pend; __VA_ARGS__; } break;   \
+        default: { using E = BobD; __VA_ARGS__; } break;            \
+    }
+
+template <bool AR, int REC>
+__global__ __launch_bounds__(BLOCK) void k_rollout_mixed(const Segs* __restrict__ segs, int k_steps, uint64_t seed) {
+    int b = blockIdx.x, q = 0, first = 0;
+    int n = segs->n;
+    while (q < n - 1 && b >= segs->s[q].block_end) first = segs->s[q++].block_end;
+    const Seg& sg = segs->s[q];
+    MIXED_DISPATCH(sg.type, (rollout_body<E, false, AR, REC>(sg.T, sg.d, k_steps, seed, sg.reset_seed, sg.epoch0, b - first)));
+}
+
+template <bool AR>
+__global__ __launch_bounds__(BLOCK) void k_step_mixed(const Segs* __restrict__ segs) {
+    int b = blockIdx.x, q = 0, first = 0;
+    int n = segs->n;
+    while (q < n - 1 && b >= segs->s[q].block_end) first = segs->s[q++].block_end;
+    const Seg& sg = segs->s[q];
+    MIXED_DISPATCH(sg.type, (step_body<E, false, AR>(sg.T, sg.d, sg.act, sg.env_stride, sg.dim_stride, sg.reset_seed, b - first)));
+}
+#endif  // VS_TU_MIXED
+
+// -------------------------------------------------------------------------------------------- params / reset kernels
+// domain_param setter (P/environments/pysim/base.py:112-124): _calc_constants + spaces + task.reset for masked lanes.
+// src == nullptr: recompute from the stored params; bcast: src is one [P] vector for every lane.
+template <class E>
+__global__ __launch_bounds__(BLOCK) void k_set_params(Task T, Dev d, const float* __restrict__ src, long pitch,
+                                                      int bcast, const uint8_t* __restrict__ mask) {
+    int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= d.ld) return;
+    if (mask && (i >= d.n || mask[i] == 0)) return;
+    int is = i < d.n ? i : d.n - 1;  // padding lanes mirror the last env (keeps them finite)
+    float p[E::P], c[E::K];
+#pragma unroll
+    for (int k = 0; k < E::P; ++k)
+        p[k] = src ? (bcast ? src[k] : src[(size_t)k * pitch + is]) : d.params[(size_t)k * d.ld + is];
+    E::calc_consts(T, p, c);
+#pragma unroll
+    for (int k = 0; k < E::P; ++k) d.params[(size_t)k * d.ld + i] = p[k];
+#pragma unroll
+    for (int k = 0; k < E::K; ++k) d.consts[(size_t)k * d.ld + i] = c[k];
+    if (bcast && i == 0) {
+#pragma unroll
+        for (int k = 0; k < E::K; ++k) d.consts_uni[k] = c[k];
+    }
+}
+
+// DomainRandomizer.randomize(N) + get_params on device; `specs` is a device copy of the spec list
+template <class E>
+__global__ __launch_bounds__(BLOCK) void k_sample_params(Task T, Dev d, const DrSpecs* __restrict__ specs,
+                                                         uint64_t seed, const uint8_t* __restrict__ mask) {
+    int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= d.n) return;
+    if (mask && mask[i] == 0) return;
+    float c[E::K];
+    redraw_lane_params<E>(T, d, specs, i, seed, 0ull, c);
+}
+
+// SimPyEnv.reset (P/environments/pysim/base.py:166-203) for masked lanes; init == nullptr samples the init space.
+// The draws of an explicit reset use episode index 0: reset(seed) is a pure function of (seed, env index), like
+// pyrado.set_seed(seed) followed by env.reset() in the reference.
+template <class E>
+__global__ __launch_bounds__(BLOCK) void k_reset(Task T, Dev d, const float* __restrict__ init, long pitch,
+                                                 int full_state, const uint8_t* __restrict__ mask, uint64_t seed) {
+    int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= d.ld) return;
+    bool valid = i < d.n;
+    if (mask && (!valid || mask[i] == 0)) return;
+    const size_t ld = d.ld;
+    float c[E::K], s[E::S], h[E::H > 0 ? E::H : 1], ob[E::O];
+    load_consts<E, false>(d, i, c, 0, E::K);
+    if (init == nullptr || !valid) {
+        reset_lane_sampled<E>(T, d, valid, i, seed, 0ull, c, s, h);
+    } else {
+        // DomainRandWrapperLive / Buffer .reset with an explicit init_state still redraws the params
+        if (d.dr_n > 0 || d.pbuf_n > 0) {
+            float s_tmp[E::S], h_tmp[E::H > 0 ? E::H : 1];
+            reset_lane_sampled<E>(T, d, true, i, seed, 0ull, c, s_tmp, h_tmp);  // params + constants (state discarded)
+        }
+        if (full_state) {
+#pragma unroll
+            for (int j = 0; j < E::S; ++j) s[j] = init[(size_t)j * pitch + i];  // copied verbatim (base.py:184-188)
+        } else {
+            float in[E::I];
+#pragma unroll
+            for (int j = 0; j < E::I; ++j) in[j] = init[(size_t)j * pitch + i];
+            E::state_from_init(in, s);
+        }
+        float p[E::P];
+#pragma unroll
+        for (int k = 0; k < E::P; ++k) p[k] = d.params[(size_t)k * ld + i];
+        E::init_hidden(T, c, p, s, h, full_state != 0);
+    }
+    E::observe(s, ob);
+    if (d.pipe.obs_on) pipe_obs<E>(d, i, 1u, 0, ob, ob);  // EnvWrapperObs.reset processes the first observation too
+#pragma unroll
+    for (int j = 0; j < E::S; ++j) d.state[j * ld + i] = s[j];
+#pragma unroll
+    for (int j = 0; j < E::H; ++j) d.hidden[j * ld + i] = h[j];
+#pragma unroll
+    for (int j = 0; j < E::O; ++j) d.obs[j * ld + i] = ob[j];
+    d.step[i] = 0;
+    d.ret[i] = 0.f;
+    d.rew[i] = 0.f;
+    d.done[i] = 0;
+    d.failed[i] = 0;
+    d.err[i] = 0;
+    d.yielded[i] = 0;
+    d.ep_idx[i] = 1u;
+}
+
+// re-derive VS_OBS from VS_STATE after a host-side `state` assignment
+template <class E>
+__global__ __launch_bounds__(BLOCK) void k_observe(Dev d) {
+    int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= d.ld) return;
+    float s[E::S], ob[E::O];
+#pragma unroll
+    for (int j = 0; j < E::S; ++j) s[j] = d.state[(size_t)j * d.ld + i];
+    E::observe(s, ob);
+    if (d.pipe.obs_on) pipe_obs<E>(d, i, d.ep_idx[i], d.step[i], ob, ob);
+#pragma unroll
+    for (int j = 0; j < E::O; ++j) d.obs[(size_t)j * d.ld + i] = ob[j];
+}
+
+}  // namespace vs
+
+// ====================================================================================================================
+// host side shared by the translation units
+// ====================================================================================================================
+struct vs_env {
+    int type = 0;
+    int device = 0;
+    vs::Task task{};
+    vs::DrSpecs dr{};                 // host copy of the live randomizer
+    vs::DrSpecs* d_specs = nullptr;   // device scratch for vs_sample_params
+    float* d_pbuf = nullptr;      // DomainRandWrapperBuffer parameter sets
+    float* d_ring = nullptr;      // ActDelayWrapper ring (Pipe::ring)
+    int rollout_variant = -1;     // vs_set_rollout_variant: -1 automatic, 0 k_rollout, 1 k_rollout_ws<256>, 2 k_rollout_ws<64>
+    int n_cu = 256;               // compute units of the device (256 on MI355X)
+    bool auto_reset = false;
+    uint64_t ar_seed = 0;
+    bool uniform = true;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    vs::Dev d{};
+    int record_mode = 1;  // vs_set_record_mode: layout of the VS_TRAJ_REC rows
+    int traj_cap = 0;     // rows
+    uint64_t epoch = 0;   // absolute step index of the action stream of vs_step_random
+    std::string err;
+    std::vector<void*> allocs;
+    void* stage = nullptr;
+    size_t stage_bytes = 0;
+    void* stage_mask = nullptr;
+    unsigned long long* d_counter = nullptr;
+};
+
+namespace vs {
+
+static inline dim3 grid_for(int ld) { return dim3((unsigned)((ld + BLOCK - 1) / BLOCK)); }
+
+enum RolloutVariant { RV_PLAIN = 0, RV_WS256 = 1, RV_WS64 = 2 };
+
+// per-family launchers: defined (explicitly instantiated) in vecsim_family.hip, one translation unit per family
+template <class E>
+struct Launch {
+    static void step(vs_env* h, const float* act, long es, long ds);
+    static void rollout(vs_env* h, int k, uint64_t seed, uint64_t ep, int rec);
+    static int variant(vs_env* h);  // RolloutVariant vs_step_random would launch for the handle's configuration
+    static void jac(vs_env* h, const float* act, long es, long ds);
+    static void set_params(vs_env* h, const float* src, long pitch, int bcast, const uint8_t* mask);
+    static void sample_params(vs_env* h, uint64_t seed, const uint8_t* mask);
+    static void reset(vs_env* h, const float* init, long pitch, int full, const uint8_t* mask, uint64_t seed);
+    static void observe(vs_env* h);
+};
+
+// mixed batches: defined in vecsim_mixed.hip
+void launch_rollout_mixed(const Segs* dev_segs, int total_blocks, hipStream_t st, bool ar, int rec, int k_steps, uint64_t seed);
+void launch_step_mixed(const Segs* dev_segs, int total_blocks, hipStream_t st, bool ar);
+
+#ifdef VS_TU_FAMILY
+// The wave-specialised kernel pays while k_rollout would leave a SIMD with a single wave (up to 256 envs per compute unit),
+// for the families whose step splits into two comparable halves (E::WS_PAYS), and needs constants that do not change
+// inside the launch.  VS_ROLLOUT_VARIANT=plain|ws|ws64 overrides for every handle (experiments).
+template <class E>
+int Launch<E>::variant(vs_env* h) {
+    if (E::FINAL == FINAL_STATE_TIME) return RV_PLAIN;
+    if (h->d.pipe.act_on || h->d.pipe.obs_on) return RV_PLAIN;
+    const bool live = h->dr.n > 0 || h->d.pbuf_n > 0;
+    if (live && E::REWARD_SIDE_USES_CONSTS) return RV_PLAIN;
+    if (h->rollout_variant >= 0) return h->rollout_variant;
+    if (live && !E::WS_WITH_LIVE_DR) return RV_PLAIN;
+    static const char* force = getenv("VS_ROLLOUT_VARIANT");
+    if (force && force[0] == 'p') return RV_PLAIN;
+    if (force && force[0] == 'w') return force[1] && force[2] == '6' ? RV_WS64 : RV_WS256;
+    if (!E::WS_PAYS) return RV_PLAIN;
+    // one 256-env workgroup per CU at most: a CU that gets a second one runs four waves per SIMD and the launch waits for it
+    // (73 728 envs with records: 100 us against k_rollout's 79 us; at 65 536: 55 against 69)
+    if (h->d.ld > (int64_t)256 * h->n_cu) return RV_PLAIN;
+    // small batches: 64-env workgroups reach four times as many compute units
+    return h->d.ld <= (int64_t)64 * h->n_cu ? RV_WS64 : RV_WS256;
+}
+
+template <class E>
+void Launch<E>::step(vs_env* h, const float* act, long es, long ds) {
+    dim3 g = grid_for(h->d.ld), b(BLOCK);
+    bool uni = h->uniform && h->dr.n == 0 && h->d.pbuf_n == 0;
+#define LS(U, AR, PI) hipLaunchKernelGGL((k_step<E, U, AR, PI>), g, b, 0, h->stream, h->task, h->d, act, es, ds, h->ar_seed)
+    if (h->d.pipe.act_on || h->d.pipe.obs_on) {  // the wrapper pipeline: per-env-constant variant only
+        if (h->auto_reset) LS(false, true, true); else LS(false, false, true);
+    } else if (h->auto_reset) { if (uni) LS(true, true, false); else LS(false, true, false); }
+    else { if (uni) LS(true, false, false); else LS(false, false, false); }
+#undef LS
+}
+
+template <class E, bool U, bool AR, int NE>
+static void launch_ws(vs_env* h, int k, uint64_t seed, uint64_t ep, int rec) {
+    if constexpr (E::FINAL != FINAL_STATE_TIME) {
+        dim3 g((unsigned)(h->d.ld / NE)), b(2 * NE);
+        // R = 4 steps per exchange (measured on the headline config: R = 1 / 2 / 4 -> 68.7 / 64.8 / 62.0 us per 100 steps)
+#define LW(REC) hipLaunchKernelGGL((k_rollout_ws<E, U, AR, REC, 4, NE>), g, b, 0, h->stream, h->task, h->d, k, seed, h->ar_seed, ep)
+        if (rec == 0) LW(0); else if (rec == 1) LW(1); else LW(2);
+#undef LW
+    }
+}
+
+template <class E, bool U, bool AR, bool PI>
+static void launch_plain(vs_env* h, int k, uint64_t seed, uint64_t ep, int rec) {
+    dim3 g = grid_for(h->d.ld), b(BLOCK);
+#define LR(REC) hipLaunchKernelGGL((k_rollout<E, U, AR, REC, PI>), g, b, 0, h->stream, h->task, h->d, k, seed, h->ar_seed, ep)
+    if (rec == 0) LR(0); else if (rec == 1) LR(1); else LR(2);
+#undef LR
+}
+
+template <class E>
+void Launch<E>::rollout(vs_env* h, int k, uint64_t seed, uint64_t ep, int rec) {
+    const bool uni = h->uniform && h->dr.n == 0;
+    const bool ar = h->auto_reset;
+    const int var = variant(h);
+    if (var == RV_WS256 || var == RV_WS64) {
+#define WS(NE)                                                                                     \
+    if (uni) { if (ar) launch_ws<E, true, true, NE>(h, k, seed, ep, rec); else launch_ws<E, true, false, NE>(h, k, seed, ep, rec); } \
+    else { if (ar) launch_ws<E, false, true, NE>(h, k, seed, ep, rec); else launch_ws<E, false, false, NE>(h, k, seed, ep, rec); }
+        if (var == RV_WS64) { WS(64) } else { WS(256) }
+#undef WS
+        return;
+    }
+    if (h->d.pipe.act_on || h->d.pipe.obs_on) {
+        if (ar) launch_plain<E, false, true, true>(h, k, seed, ep, rec); else launch_plain<E, false, false, true>(h, k, seed, ep, rec);
+    } else if (uni) {
+        if (ar) launch_plain<E, true, true, false>(h, k, seed, ep, rec); else launch_plain<E, true, false, false>(h, k, seed, ep, rec);
+    } else {
+        if (ar) launch_plain<E, false, true, false>(h, k, seed, ep, rec); else launch_plain<E, false, false, false>(h, k, seed, ep, rec);
+    }
+}
+
+template <class E>
+void Launch<E>::jac(vs_env* h, const float* act, long es, long ds) {
+    bool uni = h->uniform && h->dr.n == 0 && h->d.pbuf_n == 0;
+    dim3 g = grid_for(h->d.ld), b(BLOCK);
+    if (uni) hipLaunchKernelGGL((k_step_jac<E, true>), g, b, 0, h->stream, h->task, h->d, act, es, ds);
+    else hipLaunchKernelGGL((k_step_jac<E, false>), g, b, 0, h->stream, h->task, h->d, act, es, ds);
+}
+
+template <class E>
+void Launch<E>::set_params(vs_env* h, const float* src, long pitch, int bcast, const uint8_t* mask) {
+    hipLaunchKernelGGL(k_set_params<E>, grid_for(h->d.ld), dim3(BLOCK), 0, h->stream, h->task, h->d, src, pitch, bcast, mask);
+}
+
+template <class E>
+void Launch<E>::sample_params(vs_env* h, uint64_t seed, const uint8_t* mask) {
+    hipLaunchKernelGGL(k_sample_params<E>, grid_for(h->d.ld), dim3(BLOCK), 0, h->stream, h->task, h->d,
+                       (const DrSpecs*)h->d_specs, seed, mask);
+}
+
+template <class E>
+void Launch<E>::reset(vs_env* h, const float* init, long pitch, int full, const uint8_t* mask, uint64_t seed) {
+    hipLaunchKernelGGL(k_reset<E>, grid_for(h->d.ld), dim3(BLOCK), 0, h->stream, h->task, h->d, init, pitch, full, mask, seed);
+}
+
+template <class E>
+void Launch<E>::observe(vs_env* h) {
+    hipLaunchKernelGGL(k_observe<E>, grid_for(h->d.ld), dim3(BLOCK), 0, h->stream, h->d);
+}
+#endif  // VS_TU_FAMILY
+
+}  // namespace vs

@@ -57,12 +57,18 @@ class StepSequence:
             setattr(self, k, v)
 
     @classmethod
-    def _packed(cls, observations, actions, rewards, info_src, done_last, dt, init_state):
+    def _packed(cls, observations, actions, rewards, info_src, done_last, dt, init_state, states=None,
+                actions_applied=None, th_ddot=None):
         """views into the sampler's packed arrays (rewards already float64): no copies, no validation.
         info_src = (env_name, param_names, params_row, rollout_number)"""
         ro = cls.__new__(cls)
         ro.observations, ro.actions, ro.rewards = observations, actions, rewards
-        ro.states = ro.env_infos = ro._time = ro._done = ro._info = None
+        ro.states = states  # [T + 1, S]: the state before every step and the final one (rollout.py:253, 306)
+        if actions_applied is not None:
+            ro.actions_applied = actions_applied  # [T, A]: env.limit_act(act) (rollout.py:244)
+        if th_ddot is not None:
+            ro.th_ddot = th_ddot  # [T + 1]: the fork's hidden pole acceleration before every step (rollout.py:238, 307)
+        ro.env_infos = ro._time = ro._done = ro._info = None
         ro.complete = True
         ro._info_src = info_src
         ro._dt = dt
@@ -185,7 +191,8 @@ class ParallelRolloutSampler:
     for a 288 GB device; pass a smaller value on less).  `num_workers` is accepted and ignored."""
 
     def __init__(self, env, policy, num_workers: int = 1, *, min_rollouts: int = None, min_steps: int = None,
-                 show_progress_bar: bool = False, seed=NO_SEED, batch_lanes: int = 65536, chunk: int = 128):
+                 show_progress_bar: bool = False, seed=NO_SEED, batch_lanes: int = 65536, chunk: int = 128,
+                 full_records: bool = True):
         if min_rollouts is None and min_steps is None:
             raise ValueErr(msg="At least one of min_rollouts and min_steps must be given")  # SamplerBase
         self.min_rollouts, self.min_steps = min_rollouts, min_steps
@@ -198,12 +205,20 @@ class ParallelRolloutSampler:
         self._sample_count = -1
         self._batch_lanes = int(batch_lanes)
         self._chunk = int(chunk)
+        # full_records: rollouts carry states / actions_applied / th_ddot like the reference's (rollout.py:305-325), at 13
+        # instead of 8 floats per QQube step on the device; False keeps observations / actions / rewards only
+        self._full = bool(full_records)
+        self._vecs = {}
+
+    def _drop_handles(self):
+        for v in self._vecs.values():
+            v.close()
         self._vecs = {}
 
     def reinit(self, env=None, policy=None):
         if env is not None:
             self.env = env
-            self._vecs = {}
+            self._drop_handles()
         if policy is not None:
             self.policy = policy
 
@@ -241,8 +256,12 @@ class ParallelRolloutSampler:
         from .vec_env import VecSimEnv
 
         base = inner_env(self.env)
+        # ONE handle at a time, sized to the exact lane count (the padding lanes of a bigger one would run, and record,
+        # rollouts nobody asked for); a different count closes the previous handle and its record buffers -- the
+        # min_steps loop changes its batch size every round and must not grow device memory
         key = n
         if key not in self._vecs:
+            self._drop_handles()
             ctor = dict(base._ctor)
             ctor.pop("num_envs", None)
             ctor.pop("load_experimental_tholds", None)
@@ -325,13 +344,17 @@ class ParallelRolloutSampler:
             return x if keep is None else x.index_select(dim, keep)
         done_t, st_t = v.tensor(L.VS_DONE)[0, :n], v.tensor(L.VS_STATE)[:, :n]
         rew_t = v.tensor(L.VS_REW)[0, :n]
+        H = v.dims["H"]
+        hid_t = v.tensor(L.VS_HIDDEN)[:, :n] if H else None
         use_fused = isinstance(self.policy, DummyPolicy)
         state0 = st_t.t().clone()
         T_cap = int(max_steps)
         t = 0
+        full = self._full
         if use_fused:
             # rollout() with DummyPolicy == vs_step_random: fused steps, on-device uniform actions, lanes freeze at done.
             # Consecutive launches fill ONE device-side trajectory buffer; nothing is copied to the host inside the loop.
+            v.set_record_mode(2 if full else 1)
             v.set_traj_capacity(T_cap)
             while t < T_cap:
                 k = int(min(self._chunk, T_cap - t))
@@ -341,27 +364,45 @@ class ParallelRolloutSampler:
                 if bool(done_t.bool().all()):  # one scalar sync per launch
                     break
             v.set_traj_offset(0)
-            F_rec = v.traj_layout()[0]
-            done_T = v.traj_planes()[1][:t, :n].bool()  # [T, n]
+            fields = v.record_fields()
+            done_T = v.traj_done(t, n)  # [T, n]
 
             def gather(ti, li):  # only the steps that belong to a rollout are ever read from the record planes
                 rec = v.gather_traj(ti, li)
-                return visible(rec[:, :O], 1), rec[:, O:O + A], rec[:, F_rec - 1]
+                col = lambda k: rec[:, fields[k][0]:fields[k][0] + fields[k][1]]
+                extra = (col("state"), col("act_app"), col("hidden")) if full else None
+                return visible(col("obs"), 1), col("act"), rec[:, fields["rew"][0]], extra
 
             def final_obs(length, T):  # lanes freeze at done: VS_OBS is the observation after every lane's last step
                 return visible(obs_full, 0).t()
+
+            def final_state(length, T):  # ... and VS_STATE / VS_HIDDEN the state it belongs to
+                return st_t.t(), (hid_t.t() if H else None)
         else:
             policy = self.policy.to(dev) if hasattr(self.policy, "to") else self.policy
             if hasattr(policy, "eval"):
                 policy.eval() if eval else policy.train()
-            obs_rec, act_rec, rew_rec, done_rec = [], [], [], []
+            obs_rec, act_rec, rew_rec, done_rec, st_rec, hid_rec = [], [], [], [], [], []
             alive = torch.ones(n, dtype=torch.bool, device=dev)
+            # rollout() stops stepping an env at done (rollout.py:185): finished lanes are frozen by the step kernel, so
+            # nothing the policy makes of their last observation can move them or raise their NaN flag
+            v.set_freeze_done(True)
+            # env.limit_act of the outermost env: the projection onto the act space the policy sees
+            from .spaces import BoxSpace
+
+            box_act = isinstance(self.env.act_space, BoxSpace)
+            if box_act:
+                a_lo, a_hi = (torch.as_tensor(np.asarray(b, dtype=np.float32), device=dev) for b in self.env.act_space.bounds)
             with torch.no_grad():
                 while t < T_cap:
                     obs_now = visible(obs_full, 0).t().contiguous()  # [n, O']: what the policy sees and what is recorded
                     act = policy(obs_now).to(torch.float32).reshape(n, A).contiguous()
                     obs_rec.append(obs_now)
                     act_rec.append(act)
+                    if full:
+                        st_rec.append(st_t.t().clone())
+                        if H:
+                            hid_rec.append(hid_t.t().clone())
                     v.step(act)
                     rew_rec.append(rew_t.clone())
                     done_rec.append(done_t.clone())
@@ -370,16 +411,30 @@ class ParallelRolloutSampler:
                         alive &= ~torch.stack(done_rec[-32:]).bool().any(dim=0)
                         if not bool(alive.any()):
                             break
+            v.set_freeze_done(False)
             obs_T, act_T = torch.stack(obs_rec), torch.stack(act_rec)  # [T, n, dim]
             rew_T, done_T = torch.stack(rew_rec), torch.stack(done_rec).bool()
+            if full:
+                st_T = torch.stack(st_rec)
+                hid_T = torch.stack(hid_rec) if H else None
 
             def gather(ti, li):
-                return obs_T[ti, li], act_T[ti, li], rew_T[ti, li]
+                extra = None
+                if full:
+                    a_ = act_T[ti, li]
+                    if box_act:
+                        app_ = torch.minimum(torch.maximum(a_, a_lo), a_hi)
+                    else:  # a discrete act space snaps to its closest element: per row on the host, exact and rare
+                        proj = np.stack([self.env.act_space.project_to(r) for r in a_.cpu().numpy().astype(np.float64)])
+                        app_ = torch.as_tensor(proj.astype(np.float32), device=dev).reshape(a_.shape)
+                    extra = (st_T[ti, li], app_, hid_T[ti, li] if H else a_[:, :0])
+                return obs_T[ti, li], act_T[ti, li], rew_T[ti, li], extra
 
-            def final_obs(length, T):  # vs_step keeps stepping finished lanes: take the observation recorded at t = length
-                ar_ = torch.arange(n, device=dev)
-                seen = obs_T[torch.clamp(length, max=T - 1), ar_]
-                return torch.where((length < T)[:, None], seen, visible(obs_full, 0).t())
+            def final_obs(length, T):  # finished lanes are frozen: VS_OBS is the observation after every lane's last step
+                return visible(obs_full, 0).t()
+
+            def final_state(length, T):
+                return st_t.t(), (hid_t.t() if H else None)
         v.raise_on_error()
         # ---- split into rollouts on the device: rollout j = steps 0 .. first done of lane j, packed lane-major ----
         T = t
@@ -392,14 +447,31 @@ class ParallelRolloutSampler:
         start = torch.cumsum(length, 0) - length
         k_idx = torch.arange(total, device=dev)
         t_idx = k_idx - start[lane]  # ... at time t_idx[k]
-        obs_s, act_s, rew_s = gather(t_idx, lane)
+        obs_s, act_s, rew_s, extra = gather(t_idx, lane)
         obs_all = torch.empty(total + n, obs_s.shape[1], device=dev)  # one observation more than steps per rollout
         obs_all[k_idx + lane] = obs_s
         obs_all[start + length + ar] = final_obs(length, T)
+        more = []
+        if extra is not None:
+            # states [T + 1, S] and (qcp) th_ddot [T + 1]: the value before every step and the final one, like observations
+            st_s, app_s, hid_s = extra
+            fin_s, fin_h = final_state(length, T)
+            st_all = torch.empty(total + n, S, device=dev)
+            st_all[k_idx + lane] = st_s
+            st_all[start + length + ar] = fin_s
+            more = [st_all, app_s.contiguous()]
+            if H:
+                hid_all = torch.empty(total + n, H, device=dev)
+                hid_all[k_idx + lane] = hid_s
+                hid_all[start + length + ar] = fin_h
+                more.append(hid_all)
         # device -> host through pinned staging buffers (a pageable .cpu() of ~70 MB runs at ~3 GB/s here), then one memcpy
         # each into arrays the caller owns
-        obs_p, act_p, rew_h, done_h, length_h, state0_h = self._to_host(
-            [obs_all, act_s.contiguous(), rew_s.contiguous(), done_T[first, ar].to(torch.uint8), length, state0.contiguous()])
+        host = self._to_host(
+            [obs_all, act_s.contiguous(), rew_s.contiguous(), done_T[first, ar].to(torch.uint8), length, state0.contiguous()]
+            + more)
+        obs_p, act_p, rew_h, done_h, length_h, state0_h = host[:6]
+        st_p, app_p, hid_p = (host[6], host[7], host[8] if H else None) if more else (None, None, None)
         rew_p = rew_h.astype(np.float64)  # one conversion for all rollouts
         done_last = done_h.astype(bool).tolist()
         params = v.get(L.VS_PARAMS)
@@ -407,8 +479,12 @@ class ParallelRolloutSampler:
         off_o = np.concatenate([[0], np.cumsum(length_h + 1)]).tolist()
         dt, name, pnames = base.dt, base.name, v.param_names
         packed = StepSequence._packed
+        qcp = name.startswith("qcp") and hid_p is not None  # the fork's th_ddot field exists for its cartpole only
         ros = [packed(obs_p[off_o[j]:off_o[j + 1]], act_p[off[j]:off[j + 1]], rew_p[off[j]:off[j + 1]],
-                      (name, pnames, params[j], first_index + j), done_last[j], dt, state0_h[j]) for j in range(n)]
+                      (name, pnames, params[j], first_index + j), done_last[j], dt, state0_h[j],
+                      None if st_p is None else st_p[off_o[j]:off_o[j + 1]],
+                      None if app_p is None else app_p[off[j]:off[j + 1]],
+                      hid_p[off_o[j]:off_o[j + 1], 0] if qcp else None) for j in range(n)]
         return ros
 
     def _to_host(self, tensors):

@@ -333,18 +333,7 @@ class VecSimEnv:
     def step(self, actions):
         """One SimPyEnv.step for every env. `actions`: torch CUDA tensor of shape [N, A] (row-major policy output),
         [A, N] / [A, ld] (struct-of-arrays) or [N] when A == 1."""
-        A = self.dims["A"]
-        if not hasattr(actions, "data_ptr"):
-            raise TypeErr(given=actions, expected_type="torch.Tensor (device)")
-        if not actions.is_cuda or str(actions.dtype) != "torch.float32":
-            raise TypeErr(msg="actions must be a float32 tensor on the GPU")
-        shp = tuple(actions.shape)
-        if shp == (self.n_envs, A) or (A == 1 and shp == (self.n_envs,)):
-            es, ds = (actions.stride(0), actions.stride(1)) if actions.dim() == 2 else (actions.stride(0), 0)
-        elif len(shp) == 2 and shp[0] == A and shp[1] in (self.n_envs, self.ld):
-            es, ds = actions.stride(1), actions.stride(0)
-        else:
-            raise ShapeErr(given=actions, expected_match=(self.n_envs, A))
+        es, ds = self._act_strides(actions)
         self._check(self._lib.vs_step(self._h, C.c_void_p(actions.data_ptr()), es, ds), "vs_step")
 
     def seek_random(self, step_index=0):
@@ -382,29 +371,58 @@ class VecSimEnv:
             self._check(self._lib.vs_set_traj_capacity(self._h, int(t_max)), "vs_set_traj_capacity")
             self._traj_cap = int(t_max)
 
+    def set_record_mode(self, mode=1):
+        """What a recording step_random keeps per step: 1 = [obs | act | rew], 2 = + [state | act_app | hidden] -- the
+        fields rollout() returns (P/sampling/rollout.py:305-325).  A change drops the record buffers."""
+        if int(mode) != self.record_mode:
+            self._check(self._lib.vs_set_record_mode(self._h, int(mode)), "vs_set_record_mode")
+            self._traj_cap = 0
+            self._traj_t0 = 0
+
+    @property
+    def record_mode(self):
+        return int(self._lib.vs_record_mode(self._h))
+
+    def set_freeze_done(self, on=True):
+        """step() leaves lanes alone whose done flag is set (rollout() stops at done); off: env.step() keeps stepping"""
+        self._check(self._lib.vs_set_freeze_done(self._h, int(bool(on))), "vs_set_freeze_done")
+
     def set_traj_offset(self, t0=0):
         """first record row of the next recording step_random (consecutive launches fill one long buffer)"""
         self._check(self._lib.vs_set_traj_offset(self._h, int(t0)), "vs_set_traj_offset")
         self._traj_t0 = int(t0)
 
+    _VARIANTS = {None: -1, "k_rollout": 0, "k_rollout_ws": 1, "k_rollout_ws64": 2}
+
     def set_rollout_variant(self, variant=None):
-        """None: automatic; 'k_rollout' / 'k_rollout_ws' pin the fused kernel (bit-identical results either way)"""
-        code = {None: -1, "k_rollout": 0, "k_rollout_ws": 1}[variant]
-        self._check(self._lib.vs_set_rollout_variant(self._h, code), "vs_set_rollout_variant")
+        """None: automatic; 'k_rollout' / 'k_rollout_ws' (256-env workgroups) / 'k_rollout_ws64' (64-env workgroups) pin the
+        fused kernel (bit-identical results every way)"""
+        self._check(self._lib.vs_set_rollout_variant(self._h, self._VARIANTS[variant]), "vs_set_rollout_variant")
 
     def rollout_variant(self):
-        """'k_rollout' or 'k_rollout_ws': the kernel vs_step_random launches for the current configuration"""
-        return "k_rollout_ws" if self._lib.vs_rollout_variant(self._h) == 1 else "k_rollout"
+        """the kernel vs_step_random launches for the current configuration"""
+        return {0: "k_rollout", 1: "k_rollout_ws", 2: "k_rollout_ws64"}[self._lib.vs_rollout_variant(self._h)]
 
-    def traj_layout(self):
-        """(F, nq, h2, h1): a record is F = O + A + 1 floats [obs | act | rew], stored as nq planes of 4, h2 of 2 and h1 of 1
-        floats per env (include/vecsim.h, VS_TRAJ_REC)"""
+    def traj_layout(self, mode=None):
+        """(F, nq, h2, h1): a record is F floats -- mode 1: [obs | act | rew], mode 2: + [state | act_app | hidden] --
+        stored as nq planes of 4, h2 of 2 and h1 of 1 floats per env (include/vecsim.h, VS_TRAJ_REC)"""
         v = [C.c_int() for _ in range(4)]
-        self._check(self._lib.vs_traj_layout(L.ENV_TYPES[self.name], *[C.byref(x) for x in v]), "vs_traj_layout")
+        mode = self.record_mode if mode is None else int(mode)
+        self._check(self._lib.vs_traj_layout(L.ENV_TYPES[self.name], mode, *[C.byref(x) for x in v]), "vs_traj_layout")
         return tuple(x.value for x in v)
 
+    def record_fields(self, mode=None):
+        """{field: (first column, width)} of a record in the given mode"""
+        S, A, O, H = (self.dims[k] for k in "SAOH")
+        f = {"obs": (0, O), "act": (O, A), "rew": (O + A, 1)}
+        if (self.record_mode if mode is None else int(mode)) == 2:
+            b = O + A + 1
+            f.update(state=(b, S), act_app=(b + S, A), hidden=(b + S + A, H))
+        return f
+
     def traj_planes(self):
-        """zero-copy views of the record buffer: [(plane [T_cap, ld, w], first record column)], done [T_cap, ld] u8"""
+        """zero-copy views of the record buffers: [(plane [T_cap, ld, w], first record column)] and the done-flag words
+        i32 [ceil(T_cap / 32), ld] (bit t % 32 of word [t // 32, i] = done flag of recorded step t of env i)"""
         import torch
 
         F, nq, h2, h1 = self.traj_layout()
@@ -418,8 +436,19 @@ class VecSimEnv:
                 off += w * ld
                 col += w
         dptr = self._lib.vs_get(self._h, L.VS_TRAJ_DONE)
-        done = torch.as_tensor(_DevArray(dptr, (self._traj_cap, ld), "|u1", self), device=dev)
-        return planes, done
+        words = torch.as_tensor(_DevArray(dptr, ((self._traj_cap + 31) // 32, ld), "<i4", self), device=dev)
+        return planes, words
+
+    def traj_done(self, k_steps=None, n=None):
+        """done flags of the recorded steps as a bool tensor [T, n] on the device (unpacked from the bit words)"""
+        import torch
+
+        T = self._traj_cap if k_steps is None else int(k_steps)
+        n = self.n_envs if n is None else int(n)
+        words = self.traj_planes()[1][: (T + 31) // 32, :n]
+        shifts = torch.arange(32, device=words.device, dtype=torch.int32)
+        bits = (words[:, None, :] >> shifts[None, :, None]) & 1  # [W, 32, n]
+        return bits.reshape(-1, n)[:T].bool()
 
     def gather_traj(self, t_idx, lane_idx):
         """records [len(t_idx), F] of the (step, env) pairs given by two index tensors: reads only what is asked for"""
@@ -429,18 +458,20 @@ class VecSimEnv:
         return torch.cat([p[t_idx, lane_idx] for p, _ in planes], dim=1)
 
     def traj_tensors(self, k_steps=None, n=None):
-        """The recorded steps as torch tensors on the device: dict(obs [T, n, O], act [T, n, A], rew [T, n], done [T, n] u8).
-        `rec` ([T, n, F], one gather of the record planes) is the only copy; obs / act / rew are views of it, done is a
-        view of the library's buffer.  The caller orders its stream with the handle's (see vs_set_stream)."""
+        """The recorded steps as torch tensors on the device: dict(obs [T, n, O], act [T, n, A], rew [T, n], done [T, n] u8;
+        in record mode 2 also state [T, n, S], act_app [T, n, A], hidden [T, n, H]).  `rec` ([T, n, F], one gather of the
+        record planes) is the only copy of the records, the fields are views of it; done is unpacked from the bit words.
+        The caller orders its stream with the handle's (see vs_set_stream)."""
         import torch
 
         T = self._traj_cap if k_steps is None else int(k_steps)
         n = self.n_envs if n is None else int(n)
-        F = self.traj_layout()[0]
-        O, A = self.dims["O"], self.dims["A"]
-        planes, done = self.traj_planes()
+        planes, _ = self.traj_planes()
         rec = torch.cat([p[:T, :n] for p, _ in planes], dim=2)  # [T, n, F]
-        return dict(rec=rec, obs=rec[..., :O], act=rec[..., O:O + A], rew=rec[..., F - 1], done=done[:T, :n])
+        out = dict(rec=rec, done=self.traj_done(T, n).to(torch.uint8))
+        for k, (c0, w) in self.record_fields().items():
+            out[k] = rec[..., c0] if k == "rew" else rec[..., c0:c0 + w]
+        return out
 
     def step_random(self, k_steps=1, seed=0, record=False):
         if record and getattr(self, "_traj_t0", 0) + k_steps > self._traj_cap:
@@ -510,7 +541,7 @@ class VecSimEnv:
         """Host copies of the recorded trajectory buffers of the last step_random(record=True): dict of [T, N, dim]"""
         self.sync()
         tt = self.traj_tensors(k_steps)
-        return {k: tt[k].cpu().numpy() for k in ("obs", "act", "rew", "done")}
+        return {k: v.cpu().numpy() for k, v in tt.items() if k != "rec"}
 
     def set_episode_log(self, on=True):
         """Opt-in per-episode log (ballot-compacted ring). Off by default: see include/vecsim.h."""
@@ -593,32 +624,6 @@ class MixedVecSimEnv:
     def _check(self, rc, what):
         if rc != 0:
             raise RuntimeError(f"{what} failed ({rc}): {self._lib.vs_mixed_last_error(self._h).decode()}")
-
-    def _act_strides(self, actions):
-        A = self.dims["A"]
-        if not hasattr(actions, "data_ptr"):
-            raise TypeErr(given=actions, expected_type="torch.Tensor (device)")
-        if not actions.is_cuda or str(actions.dtype) != "torch.float32":
-            raise TypeErr(msg="actions must be a float32 tensor on the GPU")
-        shp = tuple(actions.shape)
-        if shp == (self.n_envs, A) or (A == 1 and shp == (self.n_envs,)):
-            return (actions.stride(0), actions.stride(1)) if actions.dim() == 2 else (actions.stride(0), 0)
-        if len(shp) == 2 and shp[0] == A and shp[1] in (self.n_envs, self.ld):
-            return actions.stride(1), actions.stride(0)
-        raise ShapeErr(given=actions, expected_match=(self.n_envs, A))
-
-    def step_jac(self, actions):
-        """vs_step plus the step Jacobians; returns dict(state=[N,S,S+A], rew=[N,S+A], obs=[N,O,S+A]) (host copies)."""
-        es, ds = self._act_strides(actions)
-        self._check(self._lib.vs_step_jac(self._h, C.c_void_p(actions.data_ptr()), es, ds), "vs_step_jac")
-        S, A, O = self.dims["S"], self.dims["A"], self.dims["O"]
-        out = {}
-        for key, which, rows in (("state", L.VS_JAC_STATE, S), ("rew", L.VS_JAC_REW, 1), ("obs", L.VS_JAC_OBS, O)):
-            buf = np.empty((rows * (S + A), self.ld), dtype=np.float32)
-            self._check(self._lib.vs_copy_to_host(self._h, which, buf.ctypes.data_as(C.c_void_p)), "vs_copy_to_host")
-            arr = buf[:, : self.n_envs].reshape(rows, S + A, self.n_envs).transpose(2, 0, 1)
-            out[key] = np.ascontiguousarray(arr[:, 0] if key == "rew" else arr)
-        return out
 
     def step_random(self, k_steps=1, seed=0, record=False):
         if record:

@@ -132,7 +132,9 @@ class EnvWrapper:
         return self._wrapped_env.observe(state)
 
     def limit_act(self, act):
-        return self._wrapped_env.limit_act(act)
+        # Env.limit_act of the wrapper itself (P/environments/base.py:215-222): the projection onto ITS act space --
+        # [-1, 1] for ActNormWrapper -- which is what rollout() records as the applied action (rollout.py:244)
+        return self.act_space.project_to(act)
 
     def render(self, mode=None, render_step: int = 1):
         self._wrapped_env.render(mode, render_step)

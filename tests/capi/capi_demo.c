@@ -16,13 +16,15 @@
 
 int main(void) {
     int S, A, O, P, H, I, K, F, nq, h2, h1;
-    CHECK(vs_version() >= 130);
+    CHECK(vs_version() >= 200);
     CHECK(vs_env_dims(VS_ENV_QQ_SU, &S, &A, &O, &P, &H, &I, &K) == VS_OK);
     CHECK(S == 4 && A == 1 && O == 6 && P == 11 && H == 0 && I == 4);
     CHECK(strcmp(vs_env_name(VS_ENV_QQ_SU), "qq-su") == 0);
     CHECK(strcmp(vs_param_name(VS_ENV_QQ_SU, 0), "gravity_const") == 0);
-    CHECK(vs_traj_layout(VS_ENV_QQ_SU, &F, &nq, &h2, &h1) == VS_OK && F == 8 && nq == 2 && h2 == 0 && h1 == 0);
-    CHECK(vs_traj_layout(VS_ENV_QBB, &F, &nq, &h2, &h1) == VS_OK && F == 11 && nq == 2 && h2 == 1 && h1 == 1);
+    CHECK(vs_traj_layout(VS_ENV_QQ_SU, 1, &F, &nq, &h2, &h1) == VS_OK && F == 8 && nq == 2 && h2 == 0 && h1 == 0);
+    CHECK(vs_traj_layout(VS_ENV_QBB, 1, &F, &nq, &h2, &h1) == VS_OK && F == 11 && nq == 2 && h2 == 1 && h1 == 1);
+    CHECK(vs_traj_layout(VS_ENV_QCP_SU, 2, &F, &nq, &h2, &h1) == VS_OK && F == 13 && nq == 3 && h2 == 0 && h1 == 1);
+    CHECK(vs_traj_layout(VS_ENV_QQ_SU, 3, &F, &nq, &h2, &h1) == VS_ERR_ARG);
     float nominal[32];
     CHECK(vs_nominal_params(VS_ENV_QQ_SU, 0, nominal) == VS_OK && nominal[0] > 9.8f && nominal[0] < 9.82f);
     printf("static tables ok\n");

@@ -871,12 +871,13 @@ def test_wave_specialised_rollout_kernel_equals_plain_kernel(vs, name, auto_rese
     kw = dict(KW[name])
     kw["max_steps"] = 25  # time-outs inside the window
     live_dr = {"qq-su": ("mass_pend_pole", 0.024), "qcp-su": ("pole_length", 0.16825), "qq-st": ("length_pend_pole", 0.129)}
-    for per_env in (False, True, "live-dr"):
+    for per_env, mode in ((False, 1), (True, 2), ("live-dr", 1), ("live-dr", 2)):
         if per_env == "live-dr" and not (auto_reset and name in live_dr):
             continue
-        pair = []
-        for variant in ("k_rollout", "k_rollout_ws"):
+        trio = []
+        for variant in ("k_rollout", "k_rollout_ws", "k_rollout_ws64"):
             e = vs.VecSimEnv(name, n, **kw)
+            e.set_record_mode(mode)
             if per_env is True:
                 e.set_params(np.tile(vs.nominal_params(name), (n, 1)))
             if per_env == "live-dr":  # parameters redrawn at every auto-reset inside the launches
@@ -895,25 +896,31 @@ def test_wave_specialised_rollout_kernel_equals_plain_kernel(vs, name, auto_rese
                 t += k
             e.set_traj_offset(0)
             e.step_random(5, seed=9, record=False)  # the variant without records (no observation in the message)
-            pair.append(e)
-        a, b = pair
-        ta, tb = a.traj(38), b.traj(38)
-        for key in ("obs", "act", "rew", "done"):
-            assert np.array_equal(ta[key], tb[key]), (name, key)
+            trio.append(e)
+        a = trio[0]
+        ta = a.traj(38)
+        assert set(ta) == ({"obs", "act", "rew", "done"} | ({"state", "act_app", "hidden"} if mode == 2 else set()))
         assert ta["done"].any()
-        for which in (L.VS_STATE, L.VS_OBS, L.VS_HIDDEN, L.VS_STEPCOUNT, L.VS_RETURNS, L.VS_REW, L.VS_DONE, L.VS_FAILED,
-                      L.VS_PARAMS, L.VS_CONSTS):
-            assert np.array_equal(a.get(which), b.get(which)), (name, which)
+        stats_a = a.episode_stats()
+        ra, la, ia = a.episodes()  # (clears the accumulators)
+        for b in trio[1:]:
+            tb = b.traj(38)
+            for key in ta:
+                assert np.array_equal(ta[key], tb[key]), (name, key, b.rollout_variant())
+            for which in (L.VS_STATE, L.VS_OBS, L.VS_HIDDEN, L.VS_STEPCOUNT, L.VS_RETURNS, L.VS_REW, L.VS_DONE, L.VS_FAILED,
+                          L.VS_PARAMS, L.VS_CONSTS):
+                assert np.array_equal(a.get(which), b.get(which)), (name, which)
+            for x, y in zip(stats_a, b.episode_stats()):
+                assert np.array_equal(x, y)
+            assert stats_a[0].sum() > 0
+            rb, lb, ib = b.episodes()
+            assert sorted(zip(ia.tolist(), la.tolist(), ra.tolist())) == sorted(zip(ib.tolist(), lb.tolist(), rb.tolist()))
+            assert b.error_count() == 0
         if per_env == "live-dr":
             assert len(np.unique(a.get(L.VS_PARAMS)[:, vs.param_names(name).index(live_dr[name][0])])) > n // 2
-        for x, y in zip(a.episode_stats(), b.episode_stats()):
-            assert np.array_equal(x, y)
-        ra, la, ia = a.episodes()
-        rb, lb, ib = b.episodes()
-        assert sorted(zip(ia.tolist(), la.tolist(), ra.tolist())) == sorted(zip(ib.tolist(), lb.tolist(), rb.tolist()))
-        assert len(ra) > 0 and a.error_count() == b.error_count() == 0
-        a.close()
-        b.close()
+        assert len(ra) > 0 and a.error_count() == 0
+        for e in trio:
+            e.close()
 
 
 def test_rollout_variant_selection(vs):
@@ -929,7 +936,7 @@ def test_rollout_variant_selection(vs):
     e.set_randomizer([])
     q = vs.VecSimEnv("qcp-su", 4096, **KW["qcp-su"])
     q.set_randomizer([("gravity_const", "normal", 9.81, 1.0, 1e-4, np.inf)])
-    assert q.rollout_variant() == "k_rollout_ws"  # BASELINE config 3: long episodes, the redraw is rare
+    assert q.rollout_variant() == "k_rollout_ws64"  # BASELINE config 3: long episodes, the redraw is rare
     q.close()
     b = vs.VecSimEnv("bob", 4096, **KW["bob"])
     b.set_randomizer([("gravity_const", "normal", 9.81, 1.0, 1e-4, np.inf)])
@@ -946,7 +953,7 @@ def test_rollout_variant_selection(vs):
         big = vs.VecSimEnv("qq-su", n_big, **KW["qq-su"])
         assert big.rollout_variant() == "k_rollout", n_big
         big.close()
-    for name, expect in (("omo", "k_rollout_ws"), ("qbb", "k_rollout"), ("qcp-st", "k_rollout"), ("bob", "k_rollout_ws")):
+    for name, expect in (("omo", "k_rollout_ws64"), ("qbb", "k_rollout"), ("qcp-st", "k_rollout"), ("bob", "k_rollout_ws64")):
         x = vs.VecSimEnv(name, 4096, **KW[name])
         assert x.rollout_variant() == expect, name
         x.set_rollout_variant("k_rollout_ws")
@@ -998,9 +1005,10 @@ def test_fused_kernels_fuzz_against_step_kernel(vs):
             extra = dict(simple_dynamics=bool(rng.integers(2)))
         auto_reset, act_norm, per_env = bool(rng.integers(2)), bool(rng.integers(2)), bool(rng.integers(2))
         splits = [int(x) for x in rng.integers(1, 13, size=4)]
+        mode = int(rng.integers(1, 3))
         T = sum(splits)
         ref = vs.VecSimEnv(name, n, **kw, **extra)
-        envs = {v: vs.VecSimEnv(name, n, **kw, **extra) for v in ("k_rollout", "k_rollout_ws")}
+        envs = {v: vs.VecSimEnv(name, n, **kw, **extra) for v in ("k_rollout", "k_rollout_ws", "k_rollout_ws64")}
         params = None
         if per_env:
             params = np.tile(vs.nominal_params(name, **({"long": extra["long"]} if "long" in extra else {})), (n, 1))
@@ -1014,6 +1022,7 @@ def test_fused_kernels_fuzz_against_step_kernel(vs):
         trajs = {}
         for v, e in envs.items():
             e.set_rollout_variant(v)
+            e.set_record_mode(mode)
             e.set_traj_capacity(T)
             t = 0
             for k in splits:
@@ -1021,20 +1030,34 @@ def test_fused_kernels_fuzz_against_step_kernel(vs):
                 e.step_random(k, seed=5, record=True)
                 t += k
             trajs[v] = e.traj(T)
-        a, b = trajs["k_rollout"], trajs["k_rollout_ws"]
-        for key in ("obs", "act", "rew", "done"):
-            assert np.array_equal(a[key], b[key]), (case, name, key)
+        a = trajs["k_rollout"]
+        for v in ("k_rollout_ws", "k_rollout_ws64"):
+            for key in a:
+                assert np.array_equal(a[key], trajs[v][key]), (case, name, key, v)
         alive = np.ones(n, dtype=bool)
         for t in range(T):
             assert np.array_equal(ref.get(L.VS_OBS)[alive], a["obs"][t][alive]), (case, name, t)
+            if mode == 2:  # what rollout() keeps besides obs / act / rew: state and hidden state before the step ...
+                assert np.array_equal(ref.get(L.VS_STATE)[alive], a["state"][t][alive]), (case, name, t)
+                if ref.dims["H"]:
+                    assert np.array_equal(ref.get(L.VS_HIDDEN)[alive], a["hidden"][t][alive]), (case, name, t)
+                if name != "bob-d":  # ... and env.limit_act(act): the projection onto the action box the policy sees
+                    if act_norm:
+                        lo_, hi_ = -np.ones_like(a["act"][t]), np.ones_like(a["act"][t])
+                    else:
+                        cst = ref.get(L.VS_CONSTS)
+                        amax = {"omo": cst[:, 3:4], "bob": cst[:, 7:8], "pend": cst[:, 3:4]}.get(
+                            name, np.float32({"qq-su": 4.5, "qq-st": 4.5, "qcp-su": 6.0, "qbb": 3.0}.get(name, 0.0)))
+                        lo_, hi_ = -amax * np.ones_like(a["act"][t]), amax * np.ones_like(a["act"][t])
+                    assert np.array_equal(np.clip(a["act"][t], lo_, hi_)[alive], a["act_app"][t][alive]), (case, name, t)
             ref.step(dev(a["act"][t]))
             assert np.array_equal(ref.get(L.VS_REW)[alive], a["rew"][t][alive]), (case, name, t)
             assert np.array_equal(ref.get(L.VS_DONE).astype(bool)[alive], a["done"][t].astype(bool)[alive])
             if not auto_reset:
                 alive &= ~a["done"][t].astype(bool)
         for which in (L.VS_STATE, L.VS_HIDDEN, L.VS_STEPCOUNT, L.VS_RETURNS):
-            x, y, z = (e.get(which) for e in (ref, envs["k_rollout"], envs["k_rollout_ws"]))
-            assert np.array_equal(y, z) and np.array_equal(x[alive], y[alive]), (case, name, which)
+            x, y, z, w = (e.get(which) for e in (ref, envs["k_rollout"], envs["k_rollout_ws"], envs["k_rollout_ws64"]))
+            assert np.array_equal(y, z) and np.array_equal(y, w) and np.array_equal(x[alive], y[alive]), (case, name, which)
         for e in [ref, *envs.values()]:
             assert e.error_count() == 0
             e.close()
