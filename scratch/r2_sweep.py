@@ -46,7 +46,7 @@ def run(name, n, variant, rec, chunk=100, per_env=True, live=0, iters=20, gib=1.
     rate = n * chunk / (ms * 1e-3)
     d = dict(DIMS[name])
     bps = bytes_fused_step(d, chunk, rec) if rec < 2 else (4 * (d["O"] + 2 * d["A"] + 1 + d["S"] + d["H"]) + 0.125)
-    print(f"{name:7s} n={n:8d} {got:15s} rec={rec} chunk={chunk:3d} live={live} | {ms * 1e3:9.1f} us/launch "
+    print(f"{name:7s} n={n:8d} {('auto:' if variant is None else '') + got:20s} rec={rec} chunk={chunk:3d} live={live} | {ms * 1e3:9.1f} us/launch "
           f"{ms * 1e6 / chunk:8.1f} ns/step | {rate:.3e} env-steps/s | {rate * bps / 1e9:7.0f} GB/s alg | nan={errs}", flush=True)
     return ms
 
@@ -82,6 +82,24 @@ if "cfg" in SECTIONS:
         run("qbb", 32768, var, 1)  # config 4 shard
     for var in ("k_rollout", "k_rollout_ws", "k_rollout_ws64"):
         run("qq-su", 65536, var, 1, live=7)
+
+if "auto" in SECTIONS:  # is the automatic choice the fastest?  every family x size x (auto, the three pinned kernels)
+    for name in ("omo", "bob", "qq-su", "qcp-su", "qbb", "qq-st", "pend", "bob-d"):
+        for n in (32768, 65536, 98304):
+            for var in (None, "k_rollout", "k_rollout_ws", "k_rollout_ws64"):
+                if name == "qbb" and n > 32768 and var == "k_rollout_ws64":
+                    continue
+                run(name, n, var, 1)
+    for name, live in (("qq-su", 7), ("qcp-su", 7)):
+        for n in (32768, 65536, 98304):
+            for var in (None, "k_rollout", "k_rollout_ws", "k_rollout_ws64"):
+                run(name, n, var, 1, live=live)
+
+if "mid" in SECTIONS:
+    for n in (49152, 81920, 98304, 131072):
+        for rec in (0, 1):
+            for var in ("k_rollout", "k_rollout_ws", "k_rollout_ws64"):
+                run("qq-su", n, var, rec)
 
 if "big" in SECTIONS:
     for n in (524288, 1048576):

@@ -380,6 +380,7 @@ int vs_create(int env_type, int64_t n_envs, double dt, int64_t max_steps, int de
 #ifdef VS_WS_STAMP
     CK(dalloc(h, &d.dbg, (size_t)(ld / 64) * 8));
 #endif
+
     float nominal[MAXP];
     vs_nominal_params(env_type, T.flags, nominal);
     CK(vs_set_params_uniform(h, nominal));
@@ -866,6 +867,7 @@ static bool buf_info(vs_handle h, int which, void** p, size_t* bytes) {
 #ifdef VS_WS_STAMP
         case 99: *p = d.dbg; *bytes = (size_t)(ld / 64) * 8 * 8; return true;
 #endif
+
         default: return false;
     }
 }

@@ -213,9 +213,14 @@ struct EnvDefaults {
     // ... and its reward / record wave reads per-env constants (action bounds, c_max): then the constants must not change
     // inside a launch, i.e. no live domain randomisation.  False where bounds are fixed numbers and the reward is unscaled.
     static constexpr bool REWARD_SIDE_USES_CONSTS = true;
-    // ... and whether it still pays with a live randomizer: the redraw runs on the physics wave alone while the other
-    // waits, so only for long episodes (QCartPole swing-up: ~5 000 steps per episode, +8 %; QQube: ~540, -20 %)
-    static constexpr bool WS_WITH_LIVE_DR = false;
+    // ... and the workgroup shape (envs per workgroup) it runs fastest in at one workgroup's worth of envs per compute unit
+    // (65 536 envs on MI355X; measured per family, profiles/r02_table_variants.txt): the light steps prefer 64
+    static constexpr int WS_SHAPE_FULL = 64;
+    // ... and whether 64-env workgroups still pay between 256 and 384 envs per compute unit (needs <= 168 VGPRs)
+    static constexpr bool WS_MID = true;
+    // ... and which of its two waves draws the policy's actions when steps are recorded: the physics wave where the other one
+    // is the longer (it finishes observe() and stores the records), see k_rollout_ws
+    static constexpr bool WS_DRAW_P = false;
     // Env.limit_act -> BoxSpace.project_to (P/spaces/box.py:180-184); np.clip propagates NaN (fminf/fmaxf would drop it)
     template <class R>
     __device__ static void limit_act(const float*, const float* lo, const float* hi, const R* a_raw, R* a) {
@@ -380,6 +385,8 @@ struct QQT : EnvDefaults<1> {
     static constexpr int S = 4, A = 1, O = 6, H = 0, I = 4, P = 11, K = 11, KS = 11;
     static constexpr int REW = REW_EXP, RADIAL = 1, CMAX = -1;
     static constexpr bool REWARD_SIDE_USES_CONSTS = false;
+    static constexpr bool WS_DRAW_P = true;
+    static constexpr int WS_SHAPE_FULL = 256;
     enum { C_C0, C_C1, C_C2, C_C3, C_C4, C_KM, C_RM, C_DR, C_DP, C_TH_NEG, C_TH_POS };
     __device__ static void calc_consts(const Task&, const float* p, float* c) {  // _calc_constants :70-87
         float g = p[0], Rm = p[1], km = p[2], mr = p[3], Lr = p[4], Dr = p[5], mp = p[6], Lp = p[7], Dp = p[8];
@@ -478,7 +485,8 @@ struct QcpT : EnvDefaults<1> {
     static constexpr int S = 4, A = 1, O = 5, H = 1, I = 4, P = 17, K = 16, KS = 16;
     static constexpr int REW = V == 1 ? REW_QUADR : REW_EXP, RADIAL = 1, CMAX = -1;
     static constexpr bool REWARD_SIDE_USES_CONSTS = false;
-    static constexpr bool WS_WITH_LIVE_DR = V == 0;
+    static constexpr int WS_SHAPE_FULL = 256;
+    static constexpr bool WS_MID = false;
     static constexpr bool SYMMETRIC_BOX = V == 0;
     static constexpr int FINAL = V == 1 ? FINAL_STATE_TIME : FINAL_NONE;
     enum { C_KA, C_ETA_M, C_KB, C_MTG, C_MPL2, C_MU, C_M00, C_MPL, C_M11, C_BEQ, C_BP, C_MPLG, C_TH_NEG, C_TH_POS,
@@ -684,7 +692,9 @@ __device__ inline float qbb_ik(float th, float r, float l) {
 struct Qbb : EnvDefaults<2> {
     static constexpr int S = 8, A = 2, O = 8, H = 2, I = 4, P = 20, K = 19, KS = 17;
     static constexpr int REW = REW_SCALED_EXP, RADIAL = -1;
-    static constexpr bool WS_PAYS = false;  // 17-float messages and a physics side 3x the reward side (measured: 14-22 % slower)
+    // 17-float messages, a physics side 3x the reward side and 350 VGPRs: the split pays only while each of its two waves has
+    // a SIMD of its own (up to 128 envs per compute unit: +10 %), see Launch<E>::variant
+    static constexpr bool WS_PAYS = false;
     enum { C_AM, C_BEQV, C_JEQ, C_CKIN, C_OFFX, C_OFFY, C_TXP, C_TXN, C_TYP, C_TYN, C_BDR2, C_JBR, C_MR2, C_CKMGR2,
            C_ZETA, C_XMAX, C_CMAX, C_IK_X0, C_IK_Y0 };
     static constexpr int CMAX = C_CMAX;

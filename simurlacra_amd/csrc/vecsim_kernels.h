@@ -352,17 +352,20 @@ __device__ __forceinline__ void reset_lane_sampled(const Task& T, const Dev& d, 
     E::init_hidden(T, c, nullptr, s, h, false);
 }
 
-// completed-episode append with a wavefront ballot: one atomic per wave, lanes ranked by popcount of the lower mask
+// completed-episode append: the lanes of a wave that finished take consecutive slots of the ring.  The ranking is the
+// canonical wave idiom -- one returning atomic by the first finishing lane for the whole wave's count, its result broadcast
+// with v_readfirstlane, ranks from v_mbcnt over the ballot mask -- with nothing routed through ds_bpermute (an earlier
+// __shfl-based form lost entries on MI355X in a layout-dependent way: all lanes of a wave ended up with rank 0).
 __device__ __forceinline__ void append_episode(const Dev& d, bool fin, int i, float ret, int len) {
-    unsigned long long m = __builtin_amdgcn_ballot_w64(fin);
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(fin);
     if (m == 0ull) return;
-    unsigned lane = __lane_id();
-    int leader = __ffsll((long long)m) - 1;
+    const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
     unsigned base = 0;
-    if ((int)lane == leader) base = atomicAdd(d.ep_count, (unsigned)__popcll(m));
-    base = __shfl(base, leader);
+    if (fin && rank == 0u) base = atomicAdd(d.ep_count, (unsigned)__popcll(m));
+    // the first finishing lane holds the base: the lowest set bit of m; read it from that lane into an SGPR
+    base = (unsigned)__builtin_amdgcn_readlane((int)base, __ffsll((long long)m) - 1);
     if (fin) {
-        unsigned slot = (base + (unsigned)__popcll(m & ((1ull << lane) - 1ull))) % d.ep_cap;
+        unsigned slot = (base + rank) % d.ep_cap;
         d.ep_ret[slot] = ret;
         d.ep_len[slot] = len;
         d.ep_env[slot] = i;
@@ -616,16 +619,19 @@ __device__ __forceinline__ void store_record(float* __restrict__ row, size_t ld,
 // Row offsets (vs_set_traj_offset) need not be multiples of 32: the first word is completed, not overwritten.
 struct DoneBits {
     uint32_t w;
+    __device__ __forceinline__ static uint32_t* word(const Dev& d, int i, size_t row) {
+        return d.traj_done + (row >> 5) * (size_t)d.ld + i;
+    }
     __device__ __forceinline__ void begin(const Dev& d, int i, size_t row0) {
         const unsigned b = (unsigned)(row0 & 31u);  // wave-uniform
-        w = b ? d.traj_done[(row0 >> 5) * (size_t)d.ld + i] & ((1u << b) - 1u) : 0u;
+        w = b ? *word(d, i, row0) & ((1u << b) - 1u) : 0u;
     }
     // row = absolute record row of this step; last = it is the last recorded step of the launch (both wave-uniform)
     __device__ __forceinline__ void put(const Dev& d, int i, size_t row, bool done, bool last) {
         const unsigned b = (unsigned)(row & 31u);
         w |= (done ? 1u : 0u) << b;
         if (b == 31u || last) {
-            d.traj_done[(row >> 5) * (size_t)d.ld + i] = w;
+            *word(d, i, row) = w;
             w = 0u;
         }
     }
@@ -818,21 +824,26 @@ __device__ __forceinline__ void ws_barrier() {
 //        one workgroup per compute unit (65 536 envs on 256 CUs)
 //    64  128 threads, one wave of each role on SIMDs of their own -- for batches that cannot fill the chip with 256-env
 //        workgroups (4 096 envs are 16 of those, on 16 of 256 CUs, but 64 of these)
-// The message P -> C of one step is  s_t | E::observe_p(s_t) (records only) | h_t (REC == 2) | flags : the C wave finishes
-// the observation (E::observe_c: for QQube the sin / cos of theta, which the dynamics never need) and P keeps only the trig
-// its next step reuses.
-template <class E, bool UNI, bool AR, int REC, int WS_R, int NE>
+// The message P -> C of one step is  s_t | E::observe_p(s_t) (records only) | h_t (REC == 2) | a_t (DP) | flags : the C wave
+// finishes the observation (E::observe_c: for QQube the sin / cos of theta, which the dynamics never need) and P keeps only
+// the trig its next step reuses.
+// DP ("draw on P"): the policy's action generator runs on the physics wave and the action travels in the message instead of
+// through l_act -- for the families whose C wave is the longer one once it records (QQube: its share of observe() plus the
+// record stores outweigh the Philox block per four steps; measured with the per-role cycle stamps of -DVS_WS_STAMP).
+template <class E, bool UNI, bool AR, int REC, int WS_R, int NE, bool DP>
 __global__ __launch_bounds__(2 * NE) void k_rollout_ws(Task T, Dev d, int k_steps, uint64_t seed, uint64_t reset_seed,
                                                        uint64_t epoch0) {
     static_assert(E::FINAL != FINAL_STATE_TIME, "needs the post-step state on the reward side");
     static_assert(NE == 64 || NE == 128 || NE == 256, "envs per workgroup");
+    static_assert(!DP || !E::REWARD_SIDE_USES_CONSTS, "a batch of actions is drawn ahead: the action bounds must not change at a reset");
     constexpr int HM = REC == 2 ? E::H : 0;                      // hidden state travels for the full records only
-    constexpr int M0 = E::S + (REC ? E::TRIG : 0) + HM + 1;      // message of one step
+    constexpr int AM = DP ? E::A : 0;                            // the action travels in the message when P draws it
+    constexpr int M0 = E::S + (REC ? E::TRIG : 0) + HM + AM + 1;  // message of one step
     constexpr int M = M0 % 4 == 3 ? M0 + 1 : M0;                 // 4k + 3 floats would be three LDS ops for the tail; pad to a quad
-    constexpr int TR0 = E::S, HM0 = E::S + (REC ? E::TRIG : 0);  // offsets inside the message
+    constexpr int TR0 = E::S, HM0 = E::S + (REC ? E::TRIG : 0), AM0 = HM0 + HM;  // offsets inside the message
     constexpr int NT = E::TRIG > 0 ? E::TRIG : 1, NH = E::H > 0 ? E::H : 1;
     __shared__ __attribute__((aligned(16))) float l_msg[2][WS_R][M * NE];
-    __shared__ __attribute__((aligned(16))) float l_act[2][WS_R][E::A * NE];
+    __shared__ __attribute__((aligned(16))) float l_act[DP ? 1 : 2][DP ? 1 : WS_R][DP ? 4 : E::A * NE];
     const int wave = threadIdx.x >> 6;
     const bool role_c = wave >= NE / 64;
     const int le = threadIdx.x & (NE - 1);  // env slot inside the workgroup
@@ -845,6 +856,39 @@ __global__ __launch_bounds__(2 * NE) void k_rollout_ws(Task T, Dev d, int k_step
     float alo[E::A], ahi[E::A];
     E::act_bounds(c, alo, ahi);
 
+    // The action stream (that of k_rollout): step ta takes words (ta % SPB) * A .. of block Philox(seed; env, RNG_ACT,
+    // ta / SPB).  A batch of WS_R steps spans NBLK blocks from a phase ph = epoch0 % SPB that is the same for every batch:
+    // with the last block of the previous batch carried over, every batch computes exactly NBLK new blocks,
+    // unconditionally -- no step-dependent branch inside the draw.  Run by the C wave, or by the P wave when DP.
+    constexpr unsigned SPB = 4 / E::A;
+    static_assert(WS_R % SPB == 0, "a batch is a whole number of Philox blocks");
+    constexpr int NBLK = WS_R / SPB;
+    const unsigned ph = (unsigned)(epoch0 % SPB);
+    const uint64_t blk0 = epoch0 / SPB;
+    uint4 carry = make_uint4(0, 0, 0, 0);
+    // the actions of batch bb: act_space.sample_uniform() per step (all WS_R of them: a ragged last batch ignores the rest)
+    auto draw_batch = [&](int bb, float (*a_out)[E::A]) __attribute__((always_inline)) {
+        uint32_t w[(NBLK + 1) * 4];
+        w[0] = carry.x, w[1] = carry.y, w[2] = carry.z, w[3] = carry.w;
+#pragma unroll
+        for (int q = 1; q <= NBLK; ++q) {
+            carry = Rng::philox(seed, d.idx0 + (uint32_t)i, RNG_ACT, blk0 + (uint64_t)bb * NBLK + (uint64_t)q);
+            w[4 * q] = carry.x, w[4 * q + 1] = carry.y, w[4 * q + 2] = carry.z, w[4 * q + 3] = carry.w;
+        }
+#pragma unroll
+        for (int r = 0; r < WS_R; ++r) {
+#pragma unroll
+            for (int j = 0; j < E::A; ++j) {
+                // word (ph + r) * A + j of w[]: ph is wave-uniform, so this is a chain of scalar-conditioned selects
+                uint32_t bits = w[r * E::A + j];
+#pragma unroll
+                for (unsigned p2 = 1; p2 < SPB; ++p2) bits = ph == p2 ? w[(r + p2) * E::A + j] : bits;
+                bool nrm = (T.flags & VS_FLAG_ACT_NORM) != 0;
+                a_out[r][j] = E::sample_action(c, nrm ? -1.0f : alo[j], nrm ? 1.0f : ahi[j], Rng::to_u01(bits), j);
+            }
+        }
+    };
+
     if (!role_c) {
         // ------------------------------------------------------------------------------------------- P wave
         float s[E::S], h[NH], tr[NT], ob[E::O];
@@ -856,30 +900,26 @@ __global__ __launch_bounds__(2 * NE) void k_rollout_ws(Task T, Dev d, int k_step
         uint32_t epi = d.ep_idx[i];
         bool frozen = !AR && d.done[i] != 0;
         bool done = d.done[i] != 0, failed = d.failed[i] != 0;
+        bool err_acc = false;  // the NaN flag is sticky and write-only: one store after the loop instead of a branch per step
         if (REC) E::observe_p(s, tr);
+        if (DP) carry = Rng::philox(seed, d.idx0 + (uint32_t)i, RNG_ACT, blk0);
         __builtin_amdgcn_s_waitcnt(0x0F70);
-        ws_barrier();  // the actions of batch 0 are in l_act[0]
-#ifdef VS_WS_NOP  // diagnostic: the P wave only keeps the barriers
-        for (int b = 0; b < nb; ++b) ws_barrier();
-        if (false)
-#endif
-#ifdef VS_WS_STAMP
-        unsigned long long acc0 = 0, acc1 = 0, acc2 = 0;
-#endif
-        for (int b = 0; b < nb; ++b) {
-            const int nr = min(WS_R, k_steps - b * WS_R);
-            VS_STAMP(st0);
+        ws_barrier();  // the actions of batch 0 are in l_act[0] (!DP)
+        // one batch of the P side; FULL: all WS_R steps exist (every batch but a ragged last one) -- no step guards, so that the
+        // unrolled steps form as few basic blocks as the rare reset branch allows
+        auto p_batch = [&](auto full_tag, int b, int nr) __attribute__((always_inline)) {
+            constexpr bool FULL = decltype(full_tag)::value;
             // all actions of the batch up front: one LDS round trip per batch instead of one per step on the critical path
             float a_all[WS_R][E::A];
+            if (DP) {
+                draw_batch(b, a_all);
+            } else {
 #pragma unroll
-            for (int r = 0; r < WS_R; ++r) Planes<E::A>::load(l_act[b & 1][r], NE, le, a_all[r]);
-#ifdef VS_WS_STAMP
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#endif
-            VS_STAMP(st1);
+                for (int r = 0; r < WS_R; ++r) Planes<E::A>::load(l_act[b & 1][r], NE, le, a_all[r]);
+            }
 #pragma unroll
             for (int r = 0; r < WS_R; ++r) {
-                if (r >= nr) break;
+                if (!FULL && r >= nr) continue;
                 const float* a = a_all[r];
                 float v[M];
 #pragma unroll
@@ -890,6 +930,8 @@ __global__ __launch_bounds__(2 * NE) void k_rollout_ws(Task T, Dev d, int k_step
                 }
 #pragma unroll
                 for (int j = 0; j < HM; ++j) v[HM0 + j] = h[j];
+#pragma unroll
+                for (int j = 0; j < AM; ++j) v[AM0 + j] = a[j];
                 bool fin = false;  // (used for the reset on this side)
                 if (!frozen) {
                     // the P half of step_one: ActNorm -> limit_act -> _step_dynamics -> curr_step += 1 -> is_done
@@ -909,6 +951,9 @@ __global__ __launch_bounds__(2 * NE) void k_rollout_ws(Task T, Dev d, int k_step
                     for (int j = 0; j < E::A; ++j) err |= visnan(an[j]);
                     E::limit_act(c, alo, ahi, an, ac);
                     E::dynamics(T, c, s, h, ac, (REC && E::TRIG > 0) ? (const float*)tr : (const float*)nullptr);
+                    // the trig of the new state right behind the dynamics, in the same basic block as the bounds test and the
+                    // message below: independent work for the scheduler to interleave (a lane that resets redoes it)
+                    if (REC) E::observe_p(s, tr);
                     step += 1;
                     float slo[E::S], shi[E::S];
                     E::state_bounds(c, slo, shi);
@@ -920,7 +965,7 @@ __global__ __launch_bounds__(2 * NE) void k_rollout_ws(Task T, Dev d, int k_step
                     }
                     if (E::SYMMETRIC_BOX) failed = outside_symmetric_box<E::S>(s, shi);
                     done = failed | (step >= T.max_steps);
-                    if (err && valid) d.err[i] = 1;
+                    err_acc |= err;
                     fin = done && valid;
                 }
                 unsigned fl = (done ? WSF_DONE : 0u) | (E::FINAL != FINAL_NONE && failed ? WSF_FAILED : 0u) |
@@ -937,19 +982,32 @@ __global__ __launch_bounds__(2 * NE) void k_rollout_ws(Task T, Dev d, int k_step
                             reset_lane_sampled<E>(T, d, !UNI, i, reset_seed, (uint64_t)epi, c, s, h);
                             epi += 1u;
                             step = 0;
+                            if (REC) E::observe_p(s, tr);
                         }
                         if (!UNI) E::act_bounds(c, alo, ahi);
                     }
                 } else {
                     frozen |= done;
                 }
-                if (REC) E::observe_p(s, tr);
             }
+        };
+#ifdef VS_WS_NOP  // diagnostic: the P wave only keeps the barriers
+        for (int b = 0; b < nb; ++b) ws_barrier();
+        if (false)
+#endif
+#ifdef VS_WS_STAMP
+        unsigned long long acc0 = 0, acc1 = 0, acc2 = 0;
+#endif
+        for (int b = 0; b < nb; ++b) {
+            const int nr = min(WS_R, k_steps - b * WS_R);
+            VS_STAMP(st0);
+            if (nr == WS_R) p_batch(std::true_type{}, b, nr);
+            else p_batch(std::false_type{}, b, nr);
             VS_STAMP(st2);
             ws_barrier();
 #ifdef VS_WS_STAMP
             VS_STAMP(st3);
-            acc0 += st1 - st0, acc1 += st2 - st1, acc2 += st3 - st2;
+            acc1 += st2 - st0, acc2 += st3 - st2;
 #endif
         }
 #ifdef VS_WS_STAMP
@@ -958,6 +1016,7 @@ __global__ __launch_bounds__(2 * NE) void k_rollout_ws(Task T, Dev d, int k_step
             q[0] = acc0, q[1] = acc1, q[2] = acc2, q[3] = (unsigned long long)nb;
         }
 #endif
+        if (err_acc && valid) d.err[i] = 1;
         E::observe(s, ob);
 #pragma unroll
         for (int j = 0; j < E::S; ++j) d.state[j * ld + i] = s[j];
@@ -977,59 +1036,63 @@ __global__ __launch_bounds__(2 * NE) void k_rollout_ws(Task T, Dev d, int k_step
         bool yielded = E::FINAL != FINAL_NONE ? d.yielded[i] != 0 : false;
         EpStat es{0u, d.es_count[i], d.es_retsum[i], d.es_lensum[i]};
         int len = d.step[i];
-        constexpr unsigned SPB = 4 / E::A;
-        uint4 blk = make_uint4(0, 0, 0, 0);
         DoneBits db;
         if (REC) db.begin(d, i, rec0);
-        // the actions of batch bb: act_space.sample_uniform() per step, the very stream of k_rollout
-        auto draw = [&](int bb) {
-            const int nr = min(WS_R, k_steps - bb * WS_R);
+        if (!DP) carry = Rng::philox(seed, d.idx0 + (uint32_t)i, RNG_ACT, blk0);
+        auto draw = [&](int bb) __attribute__((always_inline)) {
+            if (DP) return;
+            float a_new[WS_R][E::A];
+            draw_batch(bb, a_new);
 #pragma unroll
-            for (int r = 0; r < WS_R; ++r) {
-                if (r >= nr) break;
-                const int t = bb * WS_R + r;
-                uint64_t ta = epoch0 + (uint64_t)t;
-                unsigned sub = (unsigned)(ta % SPB);
-                if (t == 0 || sub == 0) blk = Rng::philox(seed, d.idx0 + (uint32_t)i, RNG_ACT, ta / SPB);
-                float a[E::A];
-#pragma unroll
-                for (int j = 0; j < E::A; ++j) {
-                    unsigned e = sub * E::A + j;
-                    uint32_t bits = e == 0 ? blk.x : e == 1 ? blk.y : e == 2 ? blk.z : blk.w;
-                    bool nrm = (T.flags & VS_FLAG_ACT_NORM) != 0;
-                    a[j] = E::sample_action(c, nrm ? -1.0f : alo[j], nrm ? 1.0f : ahi[j], Rng::to_u01(bits), j);
-                }
-                Planes<E::A>::store(l_act[bb & 1][r], NE, le, a);
-            }
+            for (int r = 0; r < WS_R; ++r) Planes<E::A>::store(l_act[DP ? 0 : (bb & 1)][DP ? 0 : r], NE, le, a_new[r]);
         };
-        // reward, returns and records of the steps of batch bb
-        auto work_off = [&](int bb) {
-            const int nr = min(WS_R, k_steps - bb * WS_R);
+        // Reward, returns and records of the steps of batch bb, in three passes so that the arithmetic of the WS_R steps --
+        // independent of each other -- sits in ONE basic block (instruction-level parallelism for a wave that otherwise
+        // waits on its own dependent chains), the per-step bookkeeping with its rare branches in the second, the stores last.
+        auto work_off = [&](auto full_tag, int bb, int nr) __attribute__((always_inline)) {
+            constexpr bool FULL = decltype(full_tag)::value;
+            float v[WS_R][M], a[WS_R][E::A], rw[WS_R], ob[WS_R][E::O], a_app[WS_R][E::A];
 #pragma unroll
             for (int r = 0; r < WS_R; ++r) {
-                if (r >= nr) break;
-                const int t = bb * WS_R + r;
-                float v[M], a[E::A];
-                Planes<M>::load(l_msg[bb & 1][r], NE, le, v);
-                Planes<E::A>::load(l_act[bb & 1][r], NE, le, a);
-                const unsigned fl = __float_as_uint(v[M0 - 1]);
+                if (!FULL && r >= nr) continue;
+                Planes<M>::load(l_msg[bb & 1][r], NE, le, v[r]);
+                if (DP) {
+#pragma unroll
+                    for (int j = 0; j < E::A; ++j) a[r][j] = v[r][AM0 + j];
+                } else {
+                    Planes<E::A>::load(l_act[DP ? 0 : (bb & 1)][DP ? 0 : r], NE, le, a[r]);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < WS_R; ++r) {
+                if (!FULL && r >= nr) continue;
+                float an[E::A];
+                {
+                    const bool nrm = (T.flags & VS_FLAG_ACT_NORM) != 0;
+                    float lb[E::A], ub[E::A];
+                    E::act_bounds(c, lb, ub);
+#pragma unroll
+                    for (int j = 0; j < E::A; ++j) {
+                        float m = lb[j] + (a[r][j] + 1.0f) * (ub[j] - lb[j]) * 0.5f;
+                        an[j] = vsel(nrm, m, a[r][j]);
+                    }
+                }
+                rw[r] = step_reward<E, float>(T, c, v[r], an);  // pre-step state, unclipped action (Q3)
+                if (REC) E::observe_c(v[r], v[r] + TR0, ob[r]);  // the rest of observe(s_t)
+                if (REC == 2) applied_action<E>(T, c, alo, ahi, a[r], a_app[r]);
+            }
+            bool dn[WS_R];
+#pragma unroll
+            for (int r = 0; r < WS_R; ++r) {
+                if (!FULL && r >= nr) continue;
+                const unsigned fl = __float_as_uint(v[r][M0 - 1]);
                 const bool was_frozen = !AR ? (fl & WSF_FROZEN) != 0u : false;
                 const bool done = (fl & WSF_DONE) != 0u, failed = (fl & WSF_FAILED) != 0u;
                 const bool fin = done && !was_frozen && valid;
+                dn[r] = done;
                 if (!was_frozen) {
                     len += 1;  // curr_step of the running episode, counted on this side too
-                    float an[E::A];
-                    {
-                        const bool nrm = (T.flags & VS_FLAG_ACT_NORM) != 0;
-                        float lb[E::A], ub[E::A];
-                        E::act_bounds(c, lb, ub);
-#pragma unroll
-                        for (int j = 0; j < E::A; ++j) {
-                            float m = lb[j] + (a[j] + 1.0f) * (ub[j] - lb[j]) * 0.5f;
-                            an[j] = vsel(nrm, m, a[j]);
-                        }
-                    }
-                    rew = step_reward<E, float>(T, c, v, an);  // pre-step state, unclipped action (Q3)
+                    rew = rw[r];
                     if (E::FINAL == FINAL_CONST_MALUS) {  // once per episode (final_reward.py:130-135, 165-174)
                         if (done && !yielded) {
                             if (failed) rew += -1000.0f;
@@ -1040,14 +1103,7 @@ __global__ __launch_bounds__(2 * NE) void k_rollout_ws(Task T, Dev d, int k_step
                 } else {
                     rew = 0.f;
                 }
-                if (REC) {
-                    float ob[E::O], a_app[E::A];
-                    E::observe_c(v, v + TR0, ob);  // the rest of observe(s_t)
-                    if (REC == 2) applied_action<E>(T, c, alo, ahi, a, a_app);
-                    store_record<E, REC>(d.traj_rec + (rec0 + (size_t)t) * Rec<E, REC>::F * ld, ld, i, ob, a, rew, v, a_app,
-                                         v + HM0);
-                    db.put(d, i, rec0 + (size_t)t, done, t == k_steps - 1);
-                }
+                rw[r] = rew;
                 if (__builtin_amdgcn_ballot_w64(fin) != 0ull) {
                     if (d.log_episodes) append_episode(d, fin, i, ret, len);
                     if (fin) {
@@ -1062,6 +1118,21 @@ __global__ __launch_bounds__(2 * NE) void k_rollout_ws(Task T, Dev d, int k_step
                     }
                 }
             }
+            if (REC) {
+#pragma unroll
+                for (int r = 0; r < WS_R; ++r) {
+                    if (!FULL && r >= nr) continue;
+                    const int t = bb * WS_R + r;
+                    store_record<E, REC>(d.traj_rec + (rec0 + (size_t)t) * Rec<E, REC>::F * ld, ld, i, ob[r], a[r], rw[r], v[r],
+                                         a_app[r], v[r] + HM0);
+                    db.put(d, i, rec0 + (size_t)t, dn[r], t == k_steps - 1);
+                }
+            }
+        };
+        auto work = [&](int bb) __attribute__((always_inline)) {
+            const int nr = min(WS_R, k_steps - bb * WS_R);
+            if (nr == WS_R) work_off(std::true_type{}, bb, nr);
+            else work_off(std::false_type{}, bb, nr);
         };
         __builtin_amdgcn_s_waitcnt(0x0F70);
         draw(0);
@@ -1075,7 +1146,7 @@ __global__ __launch_bounds__(2 * NE) void k_rollout_ws(Task T, Dev d, int k_step
 #endif
         for (int b = 0; b < nb; ++b) {
             VS_STAMP(st0);
-            if (b >= 1) work_off(b - 1);  // reads l_act[(b - 1) & 1] before draw(b + 1) overwrites the same buffer
+            if (b >= 1) work(b - 1);  // reads l_act[(b - 1) & 1] before draw(b + 1) overwrites the same buffer
             VS_STAMP(st1);
             if (b + 1 < nb) draw(b + 1);
             VS_STAMP(st2);
@@ -1091,7 +1162,7 @@ __global__ __launch_bounds__(2 * NE) void k_rollout_ws(Task T, Dev d, int k_step
             q[0] = acc0, q[1] = acc1, q[2] = acc2, q[3] = (unsigned long long)nb;
         }
 #endif
-        work_off(nb - 1);
+        work(nb - 1);
         d.ret[i] = ret;
         d.rew[i] = rew;
         if (E::FINAL != FINAL_NONE) d.yielded[i] = yielded;
@@ -1311,9 +1382,20 @@ void launch_rollout_mixed(const Segs* dev_segs, int total_blocks, hipStream_t st
 void launch_step_mixed(const Segs* dev_segs, int total_blocks, hipStream_t st, bool ar);
 
 #ifdef VS_TU_FAMILY
-// The wave-specialised kernel pays while k_rollout would leave a SIMD with a single wave (up to 256 envs per compute unit),
-// for the families whose step splits into two comparable halves (E::WS_PAYS), and needs constants that do not change
-// inside the launch.  VS_ROLLOUT_VARIANT=plain|ws|ws64 overrides for every handle (experiments).
+// Which fused kernel for a batch (measured on MI355X, profiles/r02_table_variants.txt; 256 compute units):
+//   * the wave-specialised kernel pays while k_rollout would leave a SIMD with a single wave, for the families whose step
+//     splits into two comparable halves, and needs constants its reward wave reads not to change inside the launch;
+//   * up to 64 envs per compute unit (16 384): 64-env workgroups -- every family (4 096 QQube envs: 43.7 against 47.9 us);
+//     the ball balancer up to 128 per CU (its two waves then have a SIMD each: +10 %; beyond that its 350 VGPRs allow no
+//     second wave per SIMD and k_rollout wins);
+//   * up to 256 envs per compute unit (65 536): 256-env workgroups (one per CU, a P and a C wave on every SIMD) or
+//     64-env ones, whichever the family runs faster (E::WS_SHAPE_FULL); with a live randomizer the 64-env shape: a
+//     resetting lane's redraw stalls one pair of waves instead of four (QQube, 7 parameters: 120 against 169 us);
+//   * up to 384 envs per compute unit (98 304): 64-env workgroups still beat k_rollout's one-and-a-half waves per SIMD
+//     (QQube: 72 against 86 us per 100 recorded steps) where the kernel's registers allow a third wave per SIMD (E::WS_MID:
+//     not the cartpole's 224);
+//   * beyond: k_rollout has two or more waves per SIMD by itself.
+// VS_ROLLOUT_VARIANT=plain|ws|ws64 overrides for every handle (experiments); vs_set_rollout_variant pins per handle.
 template <class E>
 int Launch<E>::variant(vs_env* h) {
     if (E::FINAL == FINAL_STATE_TIME) return RV_PLAIN;
@@ -1321,16 +1403,15 @@ int Launch<E>::variant(vs_env* h) {
     const bool live = h->dr.n > 0 || h->d.pbuf_n > 0;
     if (live && E::REWARD_SIDE_USES_CONSTS) return RV_PLAIN;
     if (h->rollout_variant >= 0) return h->rollout_variant;
-    if (live && !E::WS_WITH_LIVE_DR) return RV_PLAIN;
     static const char* force = getenv("VS_ROLLOUT_VARIANT");
     if (force && force[0] == 'p') return RV_PLAIN;
     if (force && force[0] == 'w') return force[1] && force[2] == '6' ? RV_WS64 : RV_WS256;
-    if (!E::WS_PAYS) return RV_PLAIN;
-    // one 256-env workgroup per CU at most: a CU that gets a second one runs four waves per SIMD and the launch waits for it
-    // (73 728 envs with records: 100 us against k_rollout's 79 us; at 65 536: 55 against 69)
-    if (h->d.ld > (int64_t)256 * h->n_cu) return RV_PLAIN;
-    // small batches: 64-env workgroups reach four times as many compute units
-    return h->d.ld <= (int64_t)64 * h->n_cu ? RV_WS64 : RV_WS256;
+    const int64_t ld = h->d.ld, cu = h->n_cu;
+    if (ld <= 64 * cu) return RV_WS64;
+    if (!E::WS_PAYS) return ld <= 128 * cu ? RV_WS64 : RV_PLAIN;
+    if (ld <= 256 * cu) return live ? RV_WS64 : (E::WS_SHAPE_FULL == 64 ? RV_WS64 : RV_WS256);
+    if (ld <= 384 * cu && E::WS_MID) return RV_WS64;
+    return RV_PLAIN;
 }
 
 template <class E>
@@ -1350,7 +1431,7 @@ static void launch_ws(vs_env* h, int k, uint64_t seed, uint64_t ep, int rec) {
     if constexpr (E::FINAL != FINAL_STATE_TIME) {
         dim3 g((unsigned)(h->d.ld / NE)), b(2 * NE);
         // R = 4 steps per exchange (measured on the headline config: R = 1 / 2 / 4 -> 68.7 / 64.8 / 62.0 us per 100 steps)
-#define LW(REC) hipLaunchKernelGGL((k_rollout_ws<E, U, AR, REC, 4, NE>), g, b, 0, h->stream, h->task, h->d, k, seed, h->ar_seed, ep)
+#define LW(REC) hipLaunchKernelGGL((k_rollout_ws<E, U, AR, REC, 4, NE, (E::WS_DRAW_P && REC != 0)>), g, b, 0, h->stream, h->task, h->d, k, seed, h->ar_seed, ep)
         if (rec == 0) LW(0); else if (rec == 1) LW(1); else LW(2);
 #undef LW
     }

@@ -924,19 +924,21 @@ def test_wave_specialised_rollout_kernel_equals_plain_kernel(vs, name, auto_rese
 
 
 def test_rollout_variant_selection(vs):
-    """automatic choice: the wave-specialised kernel below two waves of envs per SIMD, for the families it pays for, and
-    never with live randomisation / a parameter buffer / a wrapper pipeline / the state-and-time dependent final reward"""
+    """automatic choice (Launch<E>::variant): the wave-specialised kernel while k_rollout would leave SIMDs with a single
+    wave -- in 64-env workgroups up to 128 envs per compute unit (every family) and between 256 and 384, in the family's
+    faster shape at 256 -- and never with a wrapper pipeline, the state-and-time dependent final reward, or live
+    randomisation of constants its reward wave reads"""
     e = vs.VecSimEnv("qq-su", 65536, **KW["qq-su"])
     assert e.rollout_variant() == "k_rollout_ws"
     e.set_randomizer([("gravity_const", "normal", 9.81, 1.0, 1e-4, np.inf)])
-    assert e.rollout_variant() == "k_rollout"  # allowed (the C wave needs no constants) but it does not pay: short episodes
+    assert e.rollout_variant() == "k_rollout_ws64"  # a redraw stalls one pair of waves instead of four
     e.set_rollout_variant("k_rollout_ws")
     assert e.rollout_variant() == "k_rollout_ws"
     e.set_rollout_variant(None)
     e.set_randomizer([])
     q = vs.VecSimEnv("qcp-su", 4096, **KW["qcp-su"])
     q.set_randomizer([("gravity_const", "normal", 9.81, 1.0, 1e-4, np.inf)])
-    assert q.rollout_variant() == "k_rollout_ws64"  # BASELINE config 3: long episodes, the redraw is rare
+    assert q.rollout_variant() == "k_rollout_ws64"  # BASELINE config 3 at small size
     q.close()
     b = vs.VecSimEnv("bob", 4096, **KW["bob"])
     b.set_randomizer([("gravity_const", "normal", 9.81, 1.0, 1e-4, np.inf)])
@@ -949,13 +951,16 @@ def test_rollout_variant_selection(vs):
     e.set_act_pipeline(delay=0)
     assert e.rollout_variant() == "k_rollout_ws"
     e.close()
-    for n_big in (65537, 73728, 131072):  # more than one 256-env workgroup per compute unit: the plain kernel wins
+    for n_big, expect in ((65537, "k_rollout_ws64"), (98304, "k_rollout_ws64"), (98305, "k_rollout"), (131072, "k_rollout")):
         big = vs.VecSimEnv("qq-su", n_big, **KW["qq-su"])
-        assert big.rollout_variant() == "k_rollout", n_big
+        assert big.rollout_variant() == expect, n_big
         big.close()
-    for name, expect in (("omo", "k_rollout_ws64"), ("qbb", "k_rollout"), ("qcp-st", "k_rollout"), ("bob", "k_rollout_ws64")):
-        x = vs.VecSimEnv(name, 4096, **KW[name])
-        assert x.rollout_variant() == expect, name
+    for name, n, expect in (("omo", 4096, "k_rollout_ws64"), ("qbb", 4096, "k_rollout_ws64"), ("qbb", 32768, "k_rollout_ws64"),
+                            ("qbb", 65536, "k_rollout"), ("qcp-st", 4096, "k_rollout"), ("bob", 65536, "k_rollout_ws64"),
+                            ("bob", 98304, "k_rollout_ws64"), ("qcp-su", 65536, "k_rollout_ws"), ("qcp-su", 98304, "k_rollout"),
+                            ("qq-su", 4096, "k_rollout_ws64"), ("qq-su", 32768, "k_rollout_ws")):
+        x = vs.VecSimEnv(name, n, **KW[name])
+        assert x.rollout_variant() == expect, (name, n)
         x.set_rollout_variant("k_rollout_ws")
         assert x.rollout_variant() == ("k_rollout" if name == "qcp-st" else "k_rollout_ws")
         x.close()
