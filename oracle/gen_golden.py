@@ -548,6 +548,82 @@ def gen_domain_param_samples(n=24):
     return out
 
 
+def gen_jacobians(m=96, seed=1500):
+    """Step Jacobians from the FORK'S OWN autograd path: QCartPoleSwingUpSim.step_diff_state
+    (quanser_cartpole.py:257-278 -> _step_dynamics_diff 323-358 -> _dynamics_diff 360-431 through the tensor rk4 591-655) and
+    torch.autograd.grad taken exactly as the fork's rollout does (P/sampling/rollout.py:832-837):
+        obs_grad[i] = d next_state[i] / d (state, act),   rew_grad = d rew / d (state, act)
+    The fork wrote this against a torch that still had torch.solve (removed in 1.13); the harness restores that one alias
+    (torch.solve(B, A) -> (torch.linalg.solve(A, B), None)), like np.float / np.object.  Everything runs in float64 (the fork
+    casts to whatever dtype its th_ddot tensor has).
+
+    Where the fork's differentiable restatement is NOT the NumPy step it stands in for, the cases stay inside the region in
+    which the two agree (recorded in DESIGN.md section 2):
+      * rew_fn (quanser_cartpole.py:295-321) wraps only the pole-angle error and does so with `//`, which floored toward
+        zero in the fork's torch and floors toward -inf in torch >= 1.13: cases keep err_theta = pi - theta in [0, 2 pi)
+        (both give the same), and |err| <= pi in the other dimensions (RadiallySymmDesStateTask folds all of them, Q4);
+      * next states stay inside the state space (the fork's is_done uses strict bounds, irrelevant for the Jacobians).
+    Cases: nominal and randomised domain parameters, actions inside the action box and clipped (zero action gradient),
+    the voltage dead zone off (thresholds 0) and on (+-0.5 V with actions inside it), hidden pole acceleration from a
+    running episode."""
+    # torch >= 1.13 keeps `torch.solve` only as a stub that raises and names this very replacement
+    torch.solve = lambda B, A: (torch.linalg.solve(A, B), None)
+    cls, kw = ENVS["qcp-su"]
+    env = cls(**kw)
+    rng = np.random.default_rng(seed)
+    torch.manual_seed(seed)
+    randomizer = create_default_randomizer(env)
+    rec = {k: [] for k in ("params", "state", "hidden", "act", "nstate", "nhidden", "rew", "jac_state", "jac_rew")}
+    for i in range(m):
+        dp = draw_params("qcp-su", env, rng, randomizer, i % 3)
+        if i % 4 == 3:  # dead zone on
+            dp = dict(dp, voltage_thold_neg=-0.5, voltage_thold_pos=0.5)
+        env.reset(init_state=np.zeros(4), domain_param=dp)
+        env._th_ddot_tensor = torch.zeros(1, dtype=torch.float64)
+        env._create_task(dict())  # refresh the task tensors (state_des, Q, R, bounds) in float64
+        info = space_info(env)
+        hi = info["state_hi"]
+        state = np.array([rng.uniform(-0.8, 0.8) * hi[0], rng.uniform(-np.pi + 0.05, np.pi - 0.05),
+                          rng.uniform(-0.8, 0.8) * min(hi[2], np.pi), rng.uniform(-0.9, 0.9) * np.pi])
+        act = rng.uniform(-5.5, 5.5, size=1)
+        if i % 4 == 3:
+            act = rng.uniform(-0.45, 0.45, size=1)  # inside the dead zone
+        if i % 5 == 4:
+            act = np.sign(act) * rng.uniform(6.2, 9.0, size=1)  # clipped by the action box
+        hidden = rng.uniform(-60, 60, size=1)
+        st = torch.tensor(state[None, :], dtype=torch.float64, requires_grad=True)
+        at = torch.tensor(act[None, :], dtype=torch.float64, requires_grad=True)
+        thdd = torch.tensor(hidden, dtype=torch.float64)
+        nxt, rew, done, infod = env.step_diff_state(st, at, at * 0, thdd)
+        jac_s = torch.stack([torch.cat(torch.autograd.grad(nxt[:, k].sum(), [st, at], retain_graph=True), dim=1)
+                             for k in range(nxt.shape[1])], dim=1)  # rollout.py:836
+        jac_r = torch.cat(torch.autograd.grad(rew.sum(), [st, at]), dim=1)  # rollout.py:837
+        # the NumPy step from the same inputs: the value the differentiable one must reproduce in this region
+        env.state = state.copy()
+        env._curr_step = 10
+        env._th_ddot = float(hidden[0])
+        _, rew_np, _, _ = env.step(act.copy())
+        nstate_np = np.array(env.state, dtype=np.float64)
+        if not (np.allclose(nstate_np, nxt.detach().numpy()[0], rtol=1e-9, atol=1e-11) and
+                abs(rew_np - float(rew)) <= 1e-6 * max(1.0, abs(rew_np))):  # the fork keeps state_des / Q / R in float32 (pi!)
+            raise RuntimeError(f"case {i}: the fork's differentiable step and its NumPy step disagree inside the agreed region: "
+                               f"{nstate_np} vs {nxt.detach().numpy()[0]}, rew {rew_np} vs {float(rew)}")
+        rec["params"].append(params_to_vec(env, env.domain_param))
+        rec["state"].append(state)
+        rec["hidden"].append(hidden)
+        rec["act"].append(act)
+        rec["nstate"].append(nstate_np)
+        rec["nhidden"].append(np.array([float(env._th_ddot)]))
+        rec["rew"].append(float(rew_np))
+        rec["jac_state"].append(jac_s.detach().numpy()[0])  # [S, S + A]
+        rec["jac_rew"].append(jac_r.detach().numpy()[0])    # [S + A]
+    out = {k: np.array(v) for k, v in rec.items()}
+    out["dt"] = np.array(kw["dt"])
+    out["max_steps"] = np.array(kw["max_steps"])
+    out["param_names"] = np.array(param_names(env))
+    return out
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     m_step = {"omo": 256, "bob": 256, "qq-su": 256, "qcp-su": 256, "qbb": 128, "qq-st": 192, "qcp-st": 192, "pend": 192,
@@ -570,6 +646,9 @@ def main():
         np.savez_compressed(os.path.join(OUT, "variants.npz"), **gen_variants())
     if force or not os.path.exists(os.path.join(OUT, "chains.npz")):
         np.savez_compressed(os.path.join(OUT, "chains.npz"), **gen_chains())
+    if force or not os.path.exists(os.path.join(OUT, "jac_qcp_su.npz")):
+        np.savez_compressed(os.path.join(OUT, "jac_qcp_su.npz"), **gen_jacobians())
+        print("wrote jac_qcp_su", flush=True)
     if force or not os.path.exists(os.path.join(OUT, "wrappers.npz")):
         np.savez_compressed(os.path.join(OUT, "wrappers.npz"), **gen_wrappers())
     with open(os.path.join(OUT, "domain_params.json"), "w") as fh:

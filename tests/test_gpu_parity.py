@@ -923,6 +923,93 @@ def test_wave_specialised_rollout_kernel_equals_plain_kernel(vs, name, auto_rese
             e.close()
 
 
+def test_step_jacobians_against_the_forks_autograd(vs, golden_dir):
+    """vs_step_jac against tests/golden/jac_qcp_su.npz: d(s', r) / d(s, a) of QCartPoleSwingUpSim as the fork computes them
+    with torch.autograd.grad through its step_diff_state (P/sampling/rollout.py:832-837, quanser_cartpole.py:257-431), float64,
+    inside the region where that differentiable restatement and the NumPy step agree.  Forward-mode
+    fp32 on the device: the tolerance is relative to the largest entry of a Jacobian row's scale."""
+    L = vs._lib
+    g = np.load(os.path.join(golden_dir, "jac_qcp_su.npz"))
+    n = g["state"].shape[0]
+    env = vs.VecSimEnv("qcp-su", n, **KW["qcp-su"])
+    setup_lanes(env, L, g["params"], g["state"], g["hidden"], np.full(n, 10))
+    J = env.step_jac(dev(g["act"]))
+    ref = cpu_ref.make_ref("qcp-su", **KW["qcp-su"])
+    assert_state_close(ref, env.get(L.VS_STATE), g["nstate"], g["params"])
+    np.testing.assert_allclose(env.get(L.VS_REW), g["rew"], rtol=2e-5, atol=1e-9)
+    js, jr = g["jac_state"], g["jac_rew"]
+    # per output row: entries are compared relative to the row's largest magnitude (a row mixes 1.0 and 1e-5 entries)
+    scale_s = np.abs(js).max(axis=2, keepdims=True)
+    err_s = np.abs(J["state"] - js) / scale_s
+    scale_r = np.maximum(np.abs(jr).max(axis=1, keepdims=True), 1e-12)
+    err_r = np.abs(J["rew"] - jr) / scale_r
+    print(f"jacobian vs fork autograd: max row-relative error state {err_s.max():.2e}, reward {err_r.max():.2e}")
+    assert err_s.max() < 1e-6 and err_r.max() < 5e-6  # measured: 5.6e-8 / 7.0e-7
+    # structure the fork's clamp / dead-zone masks imply: no action gradient where the action was clipped or swallowed
+    clipped = np.abs(g["act"][:, 0]) > 6.0
+    tn, tp = (list(g["param_names"]).index(k) for k in ("voltage_thold_neg", "voltage_thold_pos"))
+    dead = (g["params"][:, tn] <= g["act"][:, 0]) & (g["act"][:, 0] <= g["params"][:, tp]) & (g["params"][:, tp] > 0)
+    assert clipped.sum() >= 10 and dead.sum() >= 10
+    assert np.abs(js[clipped | dead][:, :, 4]).max() == 0.0 and np.abs(J["state"][clipped | dead][:, :, 4]).max() == 0.0
+    assert np.abs(J["rew"][~clipped, 4] - jr[~clipped, 4]).max() < 1e-6  # the reward sees the unclipped action
+    env.close()
+
+
+def test_headline_launch_values_at_65536(vs):
+    """The exact launch bench.py times -- 65 536 QQubeSwingUpSim envs, per-env constants, auto-reset, every step recorded,
+    100 steps per launch, k_rollout_ws in 256-env workgroups on every compute unit -- checked for VALUES: records, final
+    buffers and episode statistics equal the plain kernel's bit for bit (and the 64-env shape's), 512 lanes of the last
+    recorded step are re-stepped by the fp64 oracle, and the record planes hold what rollout() keeps (mode 2)."""
+    L = vs._lib
+    n, T = 65536, 100
+    trio = {}
+    for variant in ("k_rollout", "k_rollout_ws", "k_rollout_ws64"):
+        e = vs.VecSimEnv("qq-su", n, **KW["qq-su"])
+        e.set_params(np.tile(vs.nominal_params("qq-su"), (n, 1)))
+        e.set_rollout_variant(variant)
+        assert e.rollout_variant() == variant
+        e.set_auto_reset(True, seed=1)
+        e.reset(seed=2)
+        e.set_record_mode(2)
+        e.set_traj_capacity(2 * T)
+        e.step_random(T, seed=3, record=True)  # rows 0 .. 99
+        e.set_traj_offset(T)
+        e.step_random(T, seed=3, record=True)  # rows 100 .. 199: a second launch continues the streams
+        trio[variant] = e
+    auto = vs.VecSimEnv("qq-su", n, **KW["qq-su"])
+    assert auto.rollout_variant() == "k_rollout_ws"  # what the automatic choice launches at this size
+    auto.close()
+    a = trio["k_rollout"]
+    tt_a = a.traj_tensors(2 * T)
+    for variant in ("k_rollout_ws", "k_rollout_ws64"):
+        b = trio[variant]
+        tt_b = b.traj_tensors(2 * T)
+        for key in ("rec", "done"):
+            assert torch.equal(tt_a[key], tt_b[key]), (variant, key)
+        for which in (L.VS_STATE, L.VS_OBS, L.VS_STEPCOUNT, L.VS_RETURNS, L.VS_REW, L.VS_DONE, L.VS_FAILED,
+                      L.VS_EPSTAT_COUNT, L.VS_EPSTAT_RETSUM, L.VS_EPSTAT_LENSUM):
+            assert np.array_equal(a.get(which), b.get(which)), (variant, which)
+        assert b.error_count() == 0
+    assert int(tt_a["done"].sum()) > 100  # episodes ended (and restarted) inside the window
+    # 512 lanes of the last recorded step against the fp64 oracle: recorded state + action -> reward, next state
+    ref = cpu_ref.make_ref("qq-su", **KW["qq-su"])
+    lanes = np.arange(0, n, n // 512)
+    last = {k: v[2 * T - 1][torch.from_numpy(lanes).cuda()].cpu().numpy().astype(np.float64) for k, v in tt_a.items()
+            if k in ("state", "act", "rew", "obs", "act_app")}
+    done_last = tt_a["done"][2 * T - 1].cpu().numpy().astype(bool)[lanes]
+    P = ref.nominal_params(len(lanes)).astype(np.float32).astype(np.float64)
+    out = ref.step(last["state"], np.zeros((len(lanes), 0)), last["act"], P, np.zeros(len(lanes), dtype=np.int64))
+    np.testing.assert_allclose(last["rew"], out["rew"], rtol=2e-5, atol=1e-12)
+    np.testing.assert_allclose(last["obs"], ref.observe(last["state"]), rtol=1e-6, atol=5e-7)
+    np.testing.assert_array_equal(last["act_app"], np.clip(last["act"], -4.5, 4.5))
+    keep = ~done_last  # lanes that did not reset: VS_STATE is the successor of the recorded state
+    got_next = a.get(L.VS_STATE)[lanes].astype(np.float64)
+    assert keep.sum() > 400
+    assert_state_close(ref, got_next[keep], out["state"][keep], P[keep])
+    for e in trio.values():
+        e.close()
+
+
 def test_rollout_variant_selection(vs):
     """automatic choice (Launch<E>::variant): the wave-specialised kernel while k_rollout would leave SIMDs with a single
     wave -- in 64-env workgroups up to 128 envs per compute unit (every family) and between 256 and 384, in the family's

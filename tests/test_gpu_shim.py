@@ -422,3 +422,145 @@ def test_package_before_torch_in_a_fresh_process(vs):
             "print('ok', obs.shape, float(torch.ones(4, device='cuda').sum()))\n") % root
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "ok (6,) 4.0" in out.stdout, out.stdout + out.stderr
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# the batched rollouts carry everything rollout() keeps per step (P/sampling/rollout.py:237-258, 305-325)
+class _DoubleObs:
+    """a stateless policy whose arithmetic is exact on the CPU and on the GPU alike: act = 2 * obs[..., :A]"""
+
+    def __init__(self, A):
+        self.A = A
+
+    def __call__(self, obs):
+        return 2.0 * obs[..., : self.A]
+
+
+class _Replay:
+    """feeds recorded actions, one time step per call: actions [T, n, A]"""
+
+    def __init__(self, actions):
+        self.actions, self.t = actions, 0
+
+    def reset(self):
+        self.t = 0
+
+    def to(self, dev):
+        self.actions = self.actions.to(dev)
+        return self
+
+    def __call__(self, obs):
+        a = self.actions[min(self.t, len(self.actions) - 1)]
+        self.t += 1
+        return a
+
+
+@pytest.mark.parametrize("name", ["omo", "bob", "qq-su", "qcp-su", "qbb", "pend"])
+def test_fused_sampler_rollouts_carry_states_applied_actions_and_hidden(vs, name):
+    """DummyPolicy (fused on the device, record mode 2): every returned StepSequence has states [T + 1, S], actions_applied
+    [T, A] and, for the cartpole, th_ddot [T + 1]; each step replays through the fp64 oracle from the recorded state"""
+    from simurlacra_amd.policies import DummyPolicy
+    from simurlacra_amd.sampling import ParallelRolloutSampler
+
+    env = vs.ENV_CLASSES[name](**dict(KW[name], max_steps=60))
+    ros = ParallelRolloutSampler(env, DummyPolicy(env.spec), 4, min_rollouts=40, seed=7).sample()
+    ref = cpu_ref.make_ref(name, **dict(KW[name], max_steps=60))
+    P = ref.nominal_params(1).astype(np.float32).astype(np.float64)
+    _, _, alo, ahi = ref.bounds(P)
+    assert len(ros) == 40
+    for ro in ros:
+        T = len(ro)
+        assert ro.states.shape == (T + 1, ref.S) and ro.actions_applied.shape == (T, ref.A)
+        np.testing.assert_array_equal(ro.states[0], ro.init_state)
+        np.testing.assert_array_equal(ro.actions_applied, np.clip(ro.actions, alo[0].astype(np.float32), ahi[0].astype(np.float32)))
+        np.testing.assert_allclose(ro.observations, ref.observe(ro.states.astype(np.float64)), rtol=1e-6, atol=5e-7)
+        if name == "qcp-su":
+            assert ro.th_ddot.shape == (T + 1,) and ro.th_ddot[0] == 0.0
+        else:
+            assert not hasattr(ro, "th_ddot")
+        if name == "qbb":
+            continue  # its hidden plate angles are not a StepSequence field: nothing to restart the oracle from
+        hid = ro.th_ddot[:-1, None].astype(np.float64) if name == "qcp-su" else np.zeros((T, 0))
+        out = ref.step(ro.states[:-1].astype(np.float64), hid, ro.actions.astype(np.float64), np.repeat(P, T, axis=0), np.arange(T))
+        np.testing.assert_allclose(ro.rewards, out["rew"], rtol=3e-5, atol=1e-9)
+        tol = 1e-5 * np.abs(out["state"]) + 2e-6 * np.maximum(1.0, np.abs(ref.bounds(np.repeat(P, T, axis=0))[1]))
+        assert (np.abs(ro.states[1:] - out["state"]) <= tol).all()
+        if name == "qcp-su":
+            np.testing.assert_allclose(ro.th_ddot[1:], out["hidden"][:, 0], rtol=2e-4, atol=2e-3)
+        assert np.array_equal(out["done"][:-1], np.zeros(T - 1, dtype=bool)) and (bool(out["done"][-1]) or T == 60)
+    lean = ParallelRolloutSampler(env, DummyPolicy(env.spec), 4, min_rollouts=8, seed=7, full_records=False).sample()
+    assert lean[0].states is None and not hasattr(lean[0], "actions_applied")  # the lean record mode stays available
+    for a, b in zip(lean, ros):
+        np.testing.assert_array_equal(a.observations, b.observations)
+        np.testing.assert_array_equal(a.rewards, b.rewards)
+
+
+@pytest.mark.parametrize("name", ["omo", "bob", "qq-su", "qcp-su", "qbb"])
+def test_batched_sampler_equals_the_one_env_rollout_field_by_field(vs, name):
+    """policy in the loop: rollout i of ParallelRolloutSampler.sample(init_states) == rollout(env, policy,
+    reset_kwargs=dict(init_state=...)) of ONE env object, every field of the StepSequence bit for bit (same step kernel,
+    a policy whose arithmetic is exact on both sides); finished lanes of the batch are frozen, not stepped on"""
+    from simurlacra_amd.sampling import ParallelRolloutSampler, rollout
+
+    kw = dict(KW[name], max_steps=40)
+    env = vs.ENV_CLASSES[name](**kw)
+    ref = cpu_ref.make_ref(name, **kw)
+    rng = np.random.default_rng(3)
+    lo, hi = ref.init_bounds(ref.nominal_params(6)) if name != "bob" else ref.init_bounds(ref.nominal_params(6), 1)
+    inits = [x.astype(np.float32).astype(np.float64) for x in rng.uniform(lo, hi)]
+    if name != "qbb":  # (its init space is polar: init states of init-space shape only)
+        # three rollouts that leave the state space after a few steps: full-state init next to a bound, moving outwards
+        p_idx, v_idx, vel = {"omo": (0, 1, 5.0), "bob": (0, 2, 2.0), "qq-su": (0, 2, 10.0), "qcp-su": (0, 2, 0.7)}[name]
+        shi = ref.bounds(ref.nominal_params(1))[1][0]
+        for frac in (0.9, 0.97, 0.995):
+            st = np.zeros(ref.S)
+            st[p_idx], st[v_idx] = frac * shi[p_idx], vel
+            inits.append(st.astype(np.float32).astype(np.float64))
+    pol = _DoubleObs(ref.A)
+    batch = ParallelRolloutSampler(env, pol, 2, min_rollouts=len(inits), seed=1).sample(init_states=inits)
+    assert len(batch) == len(inits)
+    lengths = set()
+    for ini, ro_b in zip(inits, batch):
+        one = vs.ENV_CLASSES[name](**kw)
+        ro_1 = rollout(one, pol, reset_kwargs=dict(init_state=ini.copy()))
+        lengths.add(len(ro_1))
+        assert len(ro_b) == len(ro_1)
+        obs_1 = np.stack([np.asarray(o, dtype=np.float32) for o in ro_1.observations[1:]])
+        np.testing.assert_array_equal(ro_b.observations[1:], obs_1)  # (the cartpole's reset() returns its state: quirk Q5)
+        for field in ("actions", "actions_applied", "states"):
+            np.testing.assert_array_equal(getattr(ro_b, field), np.asarray(getattr(ro_1, field), dtype=np.float32), err_msg=field)
+        np.testing.assert_array_equal(ro_b.rewards, np.asarray(ro_1.rewards, dtype=np.float64))
+        assert ro_b.done[-1] == ro_1.done[-1]
+    assert len(lengths) > 2 or name == "qbb"  # rollouts of different lengths shared the batch: finished lanes were frozen
+
+
+@pytest.mark.parametrize("name", ["bob", "qq-su", "qcp-su"])
+def test_batched_sampler_follows_the_golden_trajectories(vs, golden_dir, name):
+    """the reference's own trajectories through the batched sampler: init states and domain parameters of
+    tests/golden/traj_*.npz (one rollout per golden trajectory), the reference's actions replayed by the policy ->
+    StepSequence.states / rewards / th_ddot against the reference's over the first steps (closed loop: fp32 rounding grows
+    along a trajectory, hence the short horizon and the looser bound than the one-step tests)"""
+    from simurlacra_amd.sampling import ParallelRolloutSampler
+
+    g = np.load(os.path.join(golden_dir, f"traj_{name.replace('-', '_')}.npz"))
+    n, horizon = g["init"].shape[0], 12
+    env = vs.ENV_CLASSES[name](**dict(KW[name], max_steps=horizon))
+    names = list(env.get_nominal_domain_param().keys())
+    long_ones = 0
+    for i in range(n):  # one domain-parameter set per sample() call: init_states x domain_params is a Cartesian product
+        acts = torch.from_numpy(np.ascontiguousarray(g["act"][i:i + 1, :horizon].transpose(1, 0, 2)).astype(np.float32))
+        s = ParallelRolloutSampler(env, _Replay(acts), 1, min_rollouts=1, seed=0)
+        (ro,) = s.sample(init_states=[g["init"][i].copy()], domain_params=[dict(zip(names, g["params"][i]))])
+        dn = np.flatnonzero(g["done"][i, : int(g["length"][i])])  # (the golden trajectories run a few steps past done)
+        t_ref = min(int(dn[0]) + 1 if len(dn) else int(g["length"][i]), horizon)
+        assert len(ro) == t_ref  # the rollout ends where the reference's does
+        T = t_ref
+        long_ones += T >= 5
+        shi = np.maximum(1.0, np.abs(g["state"][i, : T + 1]).max(axis=0))  # (rows beyond the episode's end are padding)
+        err = np.abs(ro.states[: T + 1] - g["state"][i, : T + 1])
+        assert (err <= 2e-5 * np.abs(g["state"][i, : T + 1]) + 1e-5 * shi).all(), (i, float(err.max()))
+        np.testing.assert_allclose(ro.rewards[:T], g["rew"][i, :T], rtol=1e-4, atol=1e-10)
+        np.testing.assert_array_equal(ro.actions[:T], g["act"][i, :T].astype(np.float32))
+        if name == "qcp-su":
+            np.testing.assert_allclose(ro.th_ddot[: T + 1], g["hidden"][i, : T + 1, 0], rtol=5e-4, atol=5e-3)
+    assert long_ones >= n // 2

@@ -228,3 +228,41 @@ def test_ctor_and_task_variants(golden_dir, tag):
         lo, hi = ref.init_bounds(P[:1])
         np.testing.assert_allclose(lo[0], g[f"{tag}__init_lo"], rtol=1e-14)
         np.testing.assert_allclose(hi[0], g[f"{tag}__init_hi"], rtol=1e-14)
+
+
+def test_oracle_derivatives_match_the_forks_autograd(golden_dir):
+    """central finite differences of the oracle's step (fp64) against the Jacobians the fork computes with torch.autograd
+    through its differentiable QCartPole step (tests/golden/jac_qcp_su.npz, oracle/gen_golden.py:gen_jacobians): pins the
+    derivative structure of the restatement -- RK4 with the th_ddot chain, clip and dead zone (zero action gradient), the
+    reward on the unclipped action -- to the reference, not only its values"""
+    g = np.load(os.path.join(golden_dir, "jac_qcp_su.npz"))
+    ref = cpu_ref.make_ref("qcp-su", float(g["dt"]), int(g["max_steps"]))
+    n, S, A = g["state"].shape[0], 4, 1
+    P, hidden, curr = g["params"], g["hidden"], np.full(n, 10)
+    x0 = np.concatenate([g["state"], g["act"]], axis=1)
+    out0 = ref.step(g["state"], hidden, g["act"], P, curr)
+    np.testing.assert_allclose(out0["state"], g["nstate"], rtol=1e-11, atol=1e-12)
+    np.testing.assert_allclose(out0["rew"], g["rew"], rtol=1e-10)
+    np.testing.assert_allclose(out0["hidden"], g["nhidden"], rtol=1e-10, atol=1e-12)
+    js = np.zeros((n, S, S + A))
+    jr = np.zeros((n, S + A))
+    h = 1e-6
+    for k in range(S + A):
+        outs = []
+        for sgn in (+1, -1):
+            x = x0.copy()
+            x[:, k] += sgn * h
+            outs.append(ref.step(x[:, :S], hidden, x[:, S:], P, curr))
+        js[:, :, k] = (outs[0]["state"] - outs[1]["state"]) / (2 * h)
+        jr[:, k] = (outs[0]["rew"] - outs[1]["rew"]) / (2 * h)
+    # kinks within h of the evaluation point (clip edge, dead-zone edge, sign of the cart velocity) spoil a finite difference
+    tn, tp = (list(g["param_names"]).index(k) for k in ("voltage_thold_neg", "voltage_thold_pos"))
+    a = g["act"][:, 0]
+    near = (np.abs(np.abs(a) - 6.0) < 1e-4) | (np.abs(a - P[:, tn]) < 1e-4) | (np.abs(a - P[:, tp]) < 1e-4) | \
+           (np.abs(g["state"][:, 2]) < 1e-4)
+    assert near.sum() <= 2
+    ok = ~near
+    scale = np.abs(g["jac_state"]).max(axis=2, keepdims=True)
+    assert (np.abs(js - g["jac_state"]) / scale)[ok].max() < 1e-7
+    # the fork keeps state_des / Q / R in float32 (pi rounded to 24 bits): its reward gradient carries that rounding
+    assert (np.abs(jr - g["jac_rew"]) / np.abs(g["jac_rew"]).max(axis=1, keepdims=True))[ok].max() < 2e-6
