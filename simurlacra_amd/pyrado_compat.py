@@ -33,6 +33,11 @@ def to_pyrado_step_sequence(ro):
     extra = {}
     if getattr(ro, "states", None) is not None:
         extra["states"] = ro.states
+    # the fields rollout() adds besides observations / actions / rewards (P/sampling/rollout.py:305-325): the applied
+    # actions and, in the fork, the cartpole's hidden pole acceleration
+    for field in ("actions_applied", "th_ddot"):
+        if getattr(ro, field, None) is not None:
+            extra[field] = getattr(ro, field)
     if getattr(ro, "time", None) is not None:
         extra["time"] = ro.time
     return PyradoStepSequence(observations=ro.observations, actions=ro.actions, rewards=ro.rewards,

@@ -4,11 +4,14 @@ GPU parity tests proper: the HIP path, called through the C-ABI (ctypes -> libve
   (2) the oracle (oracle/cpu_ref.py, fp64) on identical seeded inputs,
   (3) size-independent properties at BASELINE.json's full sizes.
 
-Tolerances (north_star: "done masks bit-exact, state trajectories within 1e-5 relative fp32"):
-  states / observations / hidden : |got - ref| <= 1e-5 * |ref| + ATOL_S   (one step from identical inputs)
-  rewards                        : |got - ref| <= 2e-4 * |ref| + 1e-12    (exp(-cost), cost up to a few hundred)
-  done / failed masks            : bit-exact wherever the fp64 next state is further than 1e-5 (relative) from a bound,
-                                   and ALWAYS bit-exact w.r.t. the kernel's own fp32 next state.
+Tolerances (north_star: "done masks bit-exact, state trajectories within 1e-5 relative fp32"), set from what the kernels
+achieve on the reference's golden step cases (scratch/r2_errors.py on MI355X; every test prints its worst case with -s):
+  states  : |got - ref| <= 1e-5 |ref| + ATOL_FRAC * (half-width of the state box in that dimension), ATOL_FRAC = 1e-6
+            (2e-6 for the oscillator); achieved: <= 6.6e-6 relative where |ref| > 1 % of the box, <= 9.6e-7 of the box overall
+  rewards : |got - ref| <= 3e-5 |ref| (5e-5 for the two QQube tasks: exp of costs up to a few hundred); achieved <= 2.1e-5
+  hidden  : qcp th_ddot 1e-4 relative + 5e-5 (achieved 3.1e-5 relative), qbb plate angles 2e-6
+  done / failed masks : bit-exact wherever the fp64 next state is further than 1e-5 (relative) from a bound,
+                        and ALWAYS bit-exact w.r.t. the kernel's own fp32 next state.
 """
 import os
 
@@ -26,8 +29,12 @@ KW = {"omo": dict(dt=0.02, max_steps=300), "bob": dict(dt=0.01, max_steps=500), 
       "qcp-su": dict(dt=0.002, max_steps=8000), "qbb": dict(dt=0.01, max_steps=500),
       "qq-st": dict(dt=0.01, max_steps=500), "qcp-st": dict(dt=0.01, max_steps=300),
       "pend": dict(dt=0.02, max_steps=400, init_state=np.array([0.1, 0.2])), "bob-d": dict(dt=0.01, max_steps=500)}
-RTOL_S, ATOL_S = 1e-5, 2e-6  # ATOL_S is multiplied by max(1, state bound) per dimension: see state_atol()
-RTOL_R, ATOL_R = 2e-4, 1e-12
+RTOL_S, ATOL_S = 1e-5, 2e-6  # (ATOL_S: absolute floor of the secondary checks on O(1) quantities)
+RTOL_R_ANY = 5e-5  # the loosest per-family reward tolerance, for the tests that are not per family
+ATOL_FRAC = {"omo": 2e-6}  # fraction of the state box's half-width; default 1e-6
+RTOL_R = {"qq-su": 5e-5, "qq-st": 5e-5}  # default 3e-5
+ATOL_R = 1e-12
+WORST = {}  # family -> worst observed (state error / tolerance, reward relative error): printed by the tests
 
 
 @pytest.fixture(scope="module")
@@ -52,11 +59,23 @@ def dev(x):
 
 
 def assert_state_close(ref, got, exp, params):
-    """|got - exp| <= 1e-5 |exp| + 2e-6 * max(1, half-width of the state space in that dimension)"""
+    """|got - exp| <= 1e-5 |exp| + ATOL_FRAC * (half-width of the state space in that dimension)"""
     _, shi, _, _ = ref.bounds(np.asarray(params, dtype=np.float64))
-    tol = RTOL_S * np.abs(exp) + ATOL_S * np.maximum(1.0, np.abs(shi))
-    bad = np.abs(np.asarray(got, dtype=np.float64) - exp) > tol
-    assert not bad.any(), f"{bad.sum()} state elements out of tolerance, worst {np.abs(got - exp)[bad].max()}"
+    tol = RTOL_S * np.abs(exp) + ATOL_FRAC.get(ref.name, 1e-6) * np.abs(shi)
+    err = np.abs(np.asarray(got, dtype=np.float64) - exp)
+    w = WORST.setdefault(ref.name, [0.0, 0.0])
+    w[0] = max(w[0], float((err / tol).max()))
+    bad = err > tol
+    assert not bad.any(), f"{bad.sum()} state elements out of tolerance, worst {err[bad].max()} (x{(err / tol).max():.2f} the bound)"
+
+
+def assert_rew_close(name, got, exp):
+    got, exp = np.asarray(got, dtype=np.float64), np.asarray(exp, dtype=np.float64)
+    big = np.abs(exp) > 1e-30
+    if big.any():
+        w = WORST.setdefault(name, [0.0, 0.0])
+        w[1] = max(w[1], float((np.abs(got - exp)[big] / np.abs(exp)[big]).max()))
+    np.testing.assert_allclose(got, exp, rtol=RTOL_R.get(name, 3e-5), atol=ATOL_R)
 
 
 def bound_margin(ref, nstate, params):
@@ -73,9 +92,10 @@ def check_step(env, L, ref, params, state, hidden, act, curr_step, exp, yielded=
     own = ref.observe(env.get(L.VS_STATE).astype(np.float64))
     np.testing.assert_allclose(env.get(L.VS_OBS), own, rtol=1e-6, atol=5e-7)
     np.testing.assert_allclose(env.get(L.VS_OBS), exp["obs"], rtol=RTOL_S, atol=1e-5)
-    np.testing.assert_allclose(env.get(L.VS_REW), exp["rew"], rtol=RTOL_R, atol=ATOL_R)
+    assert_rew_close(ref.name, env.get(L.VS_REW), exp["rew"])
     if ref.H:
-        np.testing.assert_allclose(env.get(L.VS_HIDDEN), exp["hidden"], rtol=1e-4, atol=1e-4 if ref.name.startswith("qcp") else 2e-6)
+        np.testing.assert_allclose(env.get(L.VS_HIDDEN), exp["hidden"], rtol=1e-4, atol=5e-5 if ref.name.startswith("qcp") else 2e-6)
+    print(f"[{ref.name}] worst so far: state error {WORST[ref.name][0]:.2f} x its bound, reward {WORST[ref.name][1]:.1e} relative")
     got_done = env.get(L.VS_DONE).astype(bool)
     margin = bound_margin(ref, exp["state"], params).min(axis=1)
     far = margin > 1e-5
@@ -171,7 +191,7 @@ def test_omo_final_reward_once_and_stepping_after_done(vs, golden_dir):
     for t in range(Lmin):
         env.put(L.VS_STATE, f32(g["state"][:, t]))  # follow the reference states, keep the device's episode flags
         env.step(dev(g["act"][:, t]))
-        np.testing.assert_allclose(env.get(L.VS_REW), g["rew"][:, t], rtol=RTOL_R, atol=1e-6)
+        np.testing.assert_allclose(env.get(L.VS_REW), g["rew"][:, t], rtol=RTOL_R_ANY, atol=1e-6)
         assert np.array_equal(env.get(L.VS_DONE).astype(bool), g["done"][:, t])
         saw_malus |= bool((g["rew"][:, t] < -900).any())
     assert saw_malus
@@ -347,7 +367,7 @@ def test_domain_randomization_on_device(vs, golden_dir, name):
     env.step(dev(act))
     exp = ref.step(state, hidden, act, P, np.zeros(n, dtype=np.int64))
     assert_state_close(ref, env.get(L.VS_STATE), exp["state"], P)
-    np.testing.assert_allclose(env.get(L.VS_REW), exp["rew"], rtol=RTOL_R, atol=ATOL_R)
+    np.testing.assert_allclose(env.get(L.VS_REW), exp["rew"], rtol=RTOL_R_ANY, atol=ATOL_R)
     env.close()
 
 
@@ -384,7 +404,7 @@ def test_random_rollout_kernel_with_auto_reset(vs, name):
     ep_ret, ep_len = [], []
     for t in range(T - 1):
         out = ref.step(obs[t], hidden, act[t], params, steps)
-        np.testing.assert_allclose(rew[t], out["rew"], rtol=RTOL_R, atol=1e-6 if name == "omo" else ATOL_R)  # noqa: E501
+        np.testing.assert_allclose(rew[t], out["rew"], rtol=RTOL_R_ANY, atol=1e-6 if name == "omo" else ATOL_R)  # noqa: E501
         margin = bound_margin(ref, out["state"], params).min(axis=1)
         far = margin > 1e-5
         assert np.array_equal(done[t][far], out["done"][far])
@@ -534,7 +554,7 @@ def test_full_size_qcp_65536_live_dr(vs, golden_dir):
     env.step(dev(act))
     exp = ref.step(s, h, act[sel].astype(np.float64), P, c)
     np.testing.assert_allclose(env.get(L.VS_STATE)[sel], exp["state"], rtol=RTOL_S, atol=ATOL_S)
-    np.testing.assert_allclose(env.get(L.VS_REW)[sel], exp["rew"], rtol=RTOL_R, atol=ATOL_R)
+    np.testing.assert_allclose(env.get(L.VS_REW)[sel], exp["rew"], rtol=RTOL_R_ANY, atol=ATOL_R)
     env.close()
 
 
@@ -660,7 +680,7 @@ def test_full_size_qbb_config4_rank_shard(vs):
     P = ref.nominal_params(1024).astype(np.float32).astype(np.float64)
     exp = ref.step(s0, h0, act[:1024].astype(np.float64), P, c0)
     assert_state_close(ref, env.get(L.VS_STATE)[:1024], exp["state"], P)
-    np.testing.assert_allclose(env.get(L.VS_REW)[:1024], exp["rew"], rtol=RTOL_R, atol=ATOL_R)
+    np.testing.assert_allclose(env.get(L.VS_REW)[:1024], exp["rew"], rtol=RTOL_R_ANY, atol=ATOL_R)
     np.testing.assert_allclose(env.get(L.VS_HIDDEN)[:1024], exp["hidden"], rtol=1e-4, atol=2e-6)
 
 

@@ -77,11 +77,11 @@ def test_fused_chain_against_reference_trajectories(vs, golden_dir, tag):
         tol = 1e-5 * np.abs(exp["state"]) + 2e-6 * np.maximum(1.0, np.abs(shi))
         assert (np.abs(env.get(L.VS_STATE) - exp["state"]) <= tol).all(), (tag, t)
         np.testing.assert_allclose(env.get(L.VS_OBS)[:, keep], exp["obs"], rtol=2e-5, atol=2e-5, err_msg=f"{tag} t={t}")
-        np.testing.assert_allclose(env.get(L.VS_REW), exp["rew"], rtol=2e-4, atol=1e-12)
+        np.testing.assert_allclose(env.get(L.VS_REW), exp["rew"], rtol=5e-5, atol=1e-12)
         assert np.array_equal(env.get(L.VS_DONE).astype(bool), exp["done"])
         if tag in DETERMINISTIC:
             np.testing.assert_allclose(exp["obs"], g[f"{tag}__obs"][:, t], rtol=1e-9, atol=1e-11)
-            np.testing.assert_allclose(env.get(L.VS_REW), g[f"{tag}__rew"][:, t], rtol=2e-4, atol=1e-12)
+            np.testing.assert_allclose(env.get(L.VS_REW), g[f"{tag}__rew"][:, t], rtol=5e-5, atol=1e-12)
         state, hidden = exp["state"], exp["hidden"]
         env.put(L.VS_STATE, f32(state))  # re-synchronise (fp64 -> fp32 rounding only)
         if ref.H:

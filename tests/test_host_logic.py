@@ -362,11 +362,17 @@ def test_register_with_pyrado_when_the_reference_is_importable():
 
         rng = np.random.default_rng(0)
         mine = [StepSequence._packed(rng.normal(size=(T + 1, 6)).astype(np.float32), rng.normal(size=(T, 1)).astype(np.float32),
-                                     rng.uniform(size=T), ("qq-su", ["g"], np.array([9.81]), 7), True, 0.004, np.zeros(4))
+                                     rng.uniform(size=T), ("qq-su", ["g"], np.array([9.81]), 7), True, 0.004, np.zeros(4),
+                                     states=rng.normal(size=(T + 1, 4)).astype(np.float32),
+                                     actions_applied=rng.normal(size=(T, 1)).astype(np.float32),
+                                     th_ddot=rng.normal(size=T + 1).astype(np.float32))
                 for T in (5, 9, 3)]
         theirs = to_pyrado_step_sequences(mine)
         assert all(isinstance(r, PyradoStepSequence) for r in theirs)
         for a, b in zip(mine, theirs):
+            # what the reference's rollout() puts into its StepSequence (rollout.py:305-325) arrives in Pyrado's container
+            assert np.array_equal(b.states, a.states) and np.array_equal(b.actions_applied, a.actions_applied)
+            assert np.array_equal(np.asarray(b.th_ddot).reshape(-1), a.th_ddot)
             assert b.length == len(a) and b.undiscounted_return() == pytest.approx(a.undiscounted_return(), rel=1e-12)
             assert b.discounted_return(0.9) == pytest.approx(a.discounted_return(0.9), rel=1e-6)
             assert b.done[-1] and not b.done[:-1].any() and b.rollout_info["env_name"] == "qq-su"
@@ -414,3 +420,19 @@ def test_domain_rand_wrapper_buffer_and_act_norm_host_side(golden_dir):
     np.testing.assert_allclose(an._process_act(np.array([0.0, 1.0])), [0.0, 3.0])
     np.testing.assert_allclose(an._process_act(np.array([-1.4, 0.5])), [-4.2, 1.5])
     assert vs.inner_env(an).name == "qbb" and an.obs_space == vs.inner_env(an).obs_space
+
+
+def test_mixed_env_exposes_only_what_the_c_api_has():
+    """MixedVecSimEnv wraps the vs_mixed_* entry points and nothing else (per-member data access, parameters, resets and
+    Jacobians go through the member handles): a method here without a vs_mixed_* counterpart would hand the vs_mixed
+    handle to a function that expects a vs_env"""
+    from simurlacra_amd import _lib as L
+    from simurlacra_amd.vec_env import MixedVecSimEnv
+
+    public = {k for k, v in vars(MixedVecSimEnv).items() if not k.startswith("_") and callable(v)}
+    assert public == {"step_random", "step", "time_random", "sync", "close"}
+    assert isinstance(vars(MixedVecSimEnv)["n_envs"], property)
+    mixed_api = {k for k in L.exported_symbols() if k.startswith("vs_mixed_")}
+    assert mixed_api == {"vs_mixed_create", "vs_mixed_destroy", "vs_mixed_last_error", "vs_mixed_step_random", "vs_mixed_step",
+                         "vs_mixed_time_random"}
+    assert not hasattr(MixedVecSimEnv, "step_jac") and not hasattr(MixedVecSimEnv, "dims")
