@@ -304,6 +304,8 @@ def measure(args, rank, world, local_rank, dist, rehearsal):
                 for _ in range(chunk):
                     policy_and_step()
 
+    ev_ms = []
+
     def timed(k):
         env.sync()
         torch.cuda.synchronize()
@@ -311,7 +313,11 @@ def measure(args, rank, world, local_rank, dist, rehearsal):
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
+        if args.mode == "fused":
+            env.timer_start()  # HIP events on the stream the kernels are launched on, around the very same launches
         run(k)
+        if args.mode == "fused":
+            ev_ms.append(env.timer_stop())
         env.sync()
         torch.cuda.synchronize()
         if dist:
@@ -323,7 +329,9 @@ def measure(args, rank, world, local_rank, dist, rehearsal):
     el = timed(steps)  # THE timed region: exactly `steps` launches between two barriers + synchronisations
     repeats = [timed(steps) for _ in range(3)]  # untimed by the contract: run-to-run spread of the same region
     cnt_t, rs_t, ls_t = (env.tensor(w)[0, :n] for w in (L.VS_EPSTAT_COUNT, L.VS_EPSTAT_RETSUM, L.VS_EPSTAT_LENSUM))
-    return dict(env=env, el=el, repeats=repeats, stats=(cnt_t, rs_t, ls_t), slots=slots, graph=graph is not None)
+    return dict(env=env, el=el, repeats=repeats, stats=(cnt_t, rs_t, ls_t), slots=slots, graph=graph is not None,
+                kernel_ms_timed_region=(ev_ms[0] / steps) if ev_ms else None,
+                kernel_ms_repeats=[e / steps for e in ev_ms[1:]])
 
 
 def main():
@@ -427,7 +435,8 @@ def main():
         if dryrun:
             out["dry_run"] = True
         else:
-            out["roofline"] = roofline(args, env, local_rank, d, n, chunk)
+            out["roofline"] = roofline(args, env, local_rank, d, n, chunk, m.get("kernel_ms_timed_region"))
+            out["roofline"]["kernel_ms_repeats"] = m.get("kernel_ms_repeats")
         out["cpu_baseline"] = cpu_base
         if cpu_base and out["value"]:
             out["vs_cpu_baseline"] = out["value"] / cpu_base["value"]
@@ -439,7 +448,7 @@ def main():
         dist.destroy_process_group()
 
 
-def roofline(args, env, local_rank, d, n, chunk):
+def roofline(args, env, local_rank, d, n, chunk, ms_region=None):
     """roofline of the dominant kernel (HIP events on the kernel's own stream) + the reference points beside it"""
     import ctypes
 
@@ -449,7 +458,10 @@ def roofline(args, env, local_rank, d, n, chunk):
     from simurlacra_amd import _lib as L
 
     if args.mode == "fused":
-        ms = env.time_step_kernel(iters=50, k_steps=chunk, record=bool(args.record))
+        # average launch duration of the dominant kernel: HIP events on its stream over the timed region itself (the K
+        # launches `value` is computed from); a separate back-to-back sample after the idle gap of the host-side epilogue
+        # reads up to 10 % high (clock ramp) and is kept only as a fallback
+        ms = ms_region if ms_region else env.time_step_kernel(iters=500, k_steps=chunk, record=bool(args.record))
         b_per = bytes_fused_step(d, chunk, args.record)
         units = n * chunk
         kname = env.rollout_variant()
@@ -499,7 +511,7 @@ def roofline(args, env, local_rank, d, n, chunk):
         env.set_record_mode(2)
         slot_bytes = chunk * env.traj_layout()[0] * env.ld * 4
         env.set_traj_capacity(chunk * max(1, int(np.ceil(RECORD_BUFFER_BYTES / slot_bytes))))
-        ms2 = env.time_step_kernel(iters=50, k_steps=chunk, record=True)
+        ms2 = env.time_step_kernel(iters=300, k_steps=chunk, record=True)
         b2 = bytes_fused_step(d, chunk, 2)
         roof["record2"] = {"kernel": env.rollout_variant(), "kernel_ms": ms2, "env_steps_per_s": units / (ms2 * 1e-3),
                            "alg_bytes_per_env_step": b2, "achieved": b2 * units / (ms2 * 1e-3) / 1e9,

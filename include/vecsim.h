@@ -306,6 +306,11 @@ int64_t vs_error_count(vs_handle h);
  * through the record buffer in k_steps-row slots, so a capacity beyond the 256 MiB Infinity Cache makes it an HBM stream) */
 int vs_time_step_kernel(vs_handle h, int mode, const float* actions, int64_t env_stride, int64_t dim_stride,
                         int k_steps, int record, int iters, float* avg_ms);
+/* HIP-event stopwatch on the handle's stream: vs_timer_start records an event where the stream stands, vs_timer_stop
+ * records a second one, waits for it and returns the device time between the two [ms] -- the time of exactly the launches
+ * issued in between (bench.py brackets its timed region with it: kernel time and wall time of the same launches) */
+int vs_timer_start(vs_handle h);
+int vs_timer_stop(vs_handle h, float* ms);
 /* streaming copy kernel (float4, 4 independent 16-B accesses per thread, non-temporal, one-shot grid, own stream) over
  * `bytes` of device memory: achieved GB/s read + write (in-repo HBM reference point) */
 int vs_membw_probe(int device_id, int64_t bytes, int iters, float* gbps);

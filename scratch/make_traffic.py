@@ -9,8 +9,11 @@ prof, out = sys.argv[1], sys.argv[2]
 
 
 def avg(dirname, counter, kernel):
+    import os
     vals = []
-    for f in glob.glob(f"{prof}/{dirname}/**/*counter_collection.csv", recursive=True):
+    kernel = {"k_rollout_ws64": "k_rollout_ws<"}.get(kernel, kernel)  # (the shape is a template argument of k_rollout_ws)
+    files = sorted(glob.glob(f"{prof}/{dirname}/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)
+    for f in files[-1:]:  # the newest pass only (a merged output directory may hold an older run's files too)
         for row in csv.DictReader(open(f)):
             if row["Counter_Name"] == counter and kernel in row["Kernel_Name"]:
                 vals.append(float(row["Counter_Value"]))
@@ -28,11 +31,19 @@ def block(fetch_dir, write_dir, kernel, alg_bytes, cmd):
                     f"separate --pmc passes of `{cmd}`; averages over the sampled launches"}
 
 
-bd = json.load(open(f"{prof}/bench_default.json"))
-res = {"fused_default": block("fetch", "write", bd["roofline"]["kernel"], bd["roofline"]["alg_bytes_per_launch"],
-                              "bench.py --no-cpu-baseline --steps 30 --warmup 5")}
-bs = json.load(open(f"{prof}/bench_step16m.json"))
+def last_json(path):
+    return json.loads([ln for ln in open(path).read().splitlines() if ln.startswith("{")][-1])
+
+
+bd = last_json(f"{prof}/bench_trace.json")
+import ctypes, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from simurlacra_amd import _lib as L
+res = {"lib_version": int(L.load().vs_version()),
+       "fused_default": block("fetch", "write", bd["roofline"]["kernel"], bd["roofline"]["alg_bytes_per_launch"],
+                              "bench.py --no-cpu-baseline --no-extras --steps 300 --warmup 50")}
+bs = last_json(f"{prof}/bench_step16m.json")
 res["step_16m"] = block("fetch_step16m", "write_step16m", "k_step", bs["roofline"]["alg_bytes_per_launch"],
-                        "bench.py --no-cpu-baseline --mode step --envs 16777216 --steps 30 --warmup 5")
+                        "bench.py --no-cpu-baseline --no-extras --mode step --envs 16777216 --steps 30 --warmup 5")
 json.dump(res, open(out, "w"), indent=1)
-print(json.dumps({k: round(v["ratio"], 3) for k, v in res.items()}))
+print(json.dumps({k: round(v["ratio"], 3) for k, v in res.items() if isinstance(v, dict)}))

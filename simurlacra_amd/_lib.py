@@ -81,6 +81,8 @@ _SIGNATURES = {
     "vs_error_count": (C.c_int64, [_P]),
     "vs_time_step_kernel": (C.c_int, [_P, C.c_int, _P, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int,
                                       C.POINTER(C.c_float)]),
+    "vs_timer_start": (C.c_int, [_P]),
+    "vs_timer_stop": (C.c_int, [_P, C.POINTER(C.c_float)]),
     "vs_membw_probe": (C.c_int, [C.c_int, C.c_int64, C.c_int, C.POINTER(C.c_float)]),
     "vs_memwrite_probe": (C.c_int, [C.c_int, C.c_int64, C.c_int, C.POINTER(C.c_float)]),
 }

@@ -401,6 +401,8 @@ int vs_destroy(vs_handle h) {
     if (h->stage_mask) (void)hipFree(h->stage_mask);
     if (h->d_pbuf) (void)hipFree(h->d_pbuf);
     if (h->d_ring) (void)hipFree(h->d_ring);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
     return VS_OK;
@@ -951,6 +953,27 @@ int vs_time_step_kernel(vs_handle h, int mode, const float* actions, int64_t env
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     return rc;
+}
+
+int vs_timer_start(vs_handle h) {
+    if (!h) return VS_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (!h->ev0) {
+        HIPCHK(h, hipEventCreate(&h->ev0));
+        HIPCHK(h, hipEventCreate(&h->ev1));
+    }
+    HIPCHK(h, hipEventRecord(h->ev0, h->stream));
+    return VS_OK;
+}
+
+int vs_timer_stop(vs_handle h, float* ms) {
+    if (!h || !ms) return fail(h, VS_ERR_ARG, "vs_timer_stop: NULL argument");
+    if (!h->ev0) return fail(h, VS_ERR_STATE, "vs_timer_stop: vs_timer_start has not been called");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipEventRecord(h->ev1, h->stream));
+    HIPCHK(h, hipEventSynchronize(h->ev1));
+    HIPCHK(h, hipEventElapsedTime(ms, h->ev0, h->ev1));
+    return VS_OK;
 }
 
 // mode 0: copy (read + write of `bytes`), mode 1: pure write stream

@@ -293,6 +293,7 @@ template <int V>
 struct BobT : EnvDefaults<1> {
     static constexpr int S = 4, A = 1, O = 4, H = 0, I = 4, P = 8, K = 9, KS = 9;
     static constexpr int REW = REW_SCALED_EXP, RADIAL = -1;
+    static constexpr int WS_SHAPE_FULL = V == 0 ? 256 : 64;  // (the discrete action's snap makes its reward wave the longer one)
     // DiscreteSpace.project_to (P/spaces/discrete.py:104-131): an action that is np.isclose to one of the elements is
     // kept as it is, anything else snaps to the closest element (argmin: the first of two equally close ones)
     template <class R>
@@ -386,7 +387,6 @@ struct QQT : EnvDefaults<1> {
     static constexpr int REW = REW_EXP, RADIAL = 1, CMAX = -1;
     static constexpr bool REWARD_SIDE_USES_CONSTS = false;
     static constexpr bool WS_DRAW_P = true;
-    static constexpr int WS_SHAPE_FULL = 256;
     enum { C_C0, C_C1, C_C2, C_C3, C_C4, C_KM, C_RM, C_DR, C_DP, C_TH_NEG, C_TH_POS };
     __device__ static void calc_consts(const Task&, const float* p, float* c) {  // _calc_constants :70-87
         float g = p[0], Rm = p[1], km = p[2], mr = p[3], Lr = p[4], Dr = p[5], mp = p[6], Lp = p[7], Dp = p[8];

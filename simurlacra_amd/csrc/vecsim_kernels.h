@@ -345,9 +345,14 @@ __device__ __forceinline__ void reset_lane_sampled(const Task& T, const Dev& d, 
 #pragma unroll
         for (int q = 0; q < E::K; ++q) d.consts[(size_t)q * d.ld + i] = c[q];
     }
-    Rng g(seed, d.idx0 + (uint32_t)i, RNG_INIT, epi);
     float init[E::I];
+#ifdef VS_ABLATE_RESET  // diagnostic builds only: what the reset path costs (a reset lane restarts from a fixed state)
+#pragma unroll
+    for (int j = 0; j < E::I; ++j) init[j] = 0.01f * (float)(j + 1);
+#else
+    Rng g(seed, d.idx0 + (uint32_t)i, RNG_INIT, epi);
     E::sample_init(T, c, g, init);
+#endif
     E::state_from_init(init, s);
     E::init_hidden(T, c, nullptr, s, h, false);
 }
@@ -844,6 +849,19 @@ __global__ __launch_bounds__(2 * NE) void k_rollout_ws(Task T, Dev d, int k_step
     constexpr int NT = E::TRIG > 0 ? E::TRIG : 1, NH = E::H > 0 ? E::H : 1;
     __shared__ __attribute__((aligned(16))) float l_msg[2][WS_R][M * NE];
     __shared__ __attribute__((aligned(16))) float l_act[DP ? 1 : 2][DP ? 1 : WS_R][DP ? 4 : E::A * NE];
+    // The reset stock (auto-reset only): the C wave keeps, per lane, the init-space sample of the lane's NEXT episode (and
+    // the trig of that state) ready in LDS, tagged with the episode counter it was drawn for.  A resetting lane of the P
+    // wave takes it with a handful of LDS reads instead of running Philox + sample_init + observe_p for the one or two
+    // lanes of the wave that reset; C refills the consumed entries every WS_REFILL batches, for all of them at once (many
+    // lanes per pass instead of one pass per event).  A lane that resets again before its entry was refilled (tag !=
+    // counter), and every reset under live randomisation (the init space may depend on the redrawn parameters), draws for
+    // itself as before -- the values are the same either way (same Philox counters).
+    constexpr bool STOCK = AR;
+    constexpr int SKW = E::I + (REC ? E::TRIG : 0);
+    constexpr int WS_REFILL = 8;
+    __shared__ float l_stock[STOCK ? SKW * NE : 1];
+    __shared__ uint32_t l_stag[STOCK ? NE : 1];
+    const bool stock_on = STOCK && d.dr_n == 0 && d.pbuf_n == 0;  // wave-uniform
     const int wave = threadIdx.x >> 6;
     const bool role_c = wave >= NE / 64;
     const int le = threadIdx.x & (NE - 1);  // env slot inside the workgroup
@@ -977,12 +995,30 @@ __global__ __launch_bounds__(2 * NE) void k_rollout_ws(Task T, Dev d, int k_step
                     if (__builtin_amdgcn_ballot_w64(fin) != 0ull) {
                         if (fin) {
                             load_consts<E, UNI>(d, i, c, E::KS, E::K);
-                            // live domain randomisation redraws the lane's parameters here: allowed for the families
-                            // whose C wave does not read constants (use_ws)
-                            reset_lane_sampled<E>(T, d, !UNI, i, reset_seed, (uint64_t)epi, c, s, h);
+                            bool stocked = false;
+                            if (STOCK) {
+                                const uint32_t tag = __hip_atomic_load(&l_stag[le], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                stocked = tag == epi;
+                                if (stocked) {
+                                    float init[E::I];
+#pragma unroll
+                                    for (int j = 0; j < E::I; ++j) init[j] = l_stock[j * NE + le];
+                                    if (REC) {
+#pragma unroll
+                                        for (int j = 0; j < E::TRIG; ++j) tr[j] = l_stock[(E::I + j) * NE + le];
+                                    }
+                                    E::state_from_init(init, s);
+                                    E::init_hidden(T, c, nullptr, s, h, false);
+                                }
+                            }
+                            if (!stocked) {
+                                // live domain randomisation redraws the lane's parameters here: allowed for the families
+                                // whose C wave does not read constants (use_ws)
+                                reset_lane_sampled<E>(T, d, !UNI, i, reset_seed, (uint64_t)epi, c, s, h);
+                                if (REC) E::observe_p(s, tr);
+                            }
                             epi += 1u;
                             step = 0;
-                            if (REC) E::observe_p(s, tr);
                         }
                         if (!UNI) E::act_bounds(c, alo, ahi);
                     }
@@ -1038,6 +1074,31 @@ __global__ __launch_bounds__(2 * NE) void k_rollout_ws(Task T, Dev d, int k_step
         int len = d.step[i];
         DoneBits db;
         if (REC) db.begin(d, i, rec0);
+        uint32_t c_epi = STOCK ? d.ep_idx[i] : 0u;  // the lane's episode counter as this side has seen it advance
+        uint32_t c_tag = 0xFFFFFFFFu;               // the counter the lane's stock entry was drawn for (none yet)
+        if (STOCK) l_stag[le] = 0xFFFFFFFFu;
+        auto refill = [&]() __attribute__((always_inline)) {
+            if (!STOCK) return;
+            const bool need = stock_on && valid && c_tag != c_epi;
+            if (__builtin_amdgcn_ballot_w64(need) == 0ull) return;
+            if (need) {
+                // SimPyEnv.reset's init_space.sample_uniform() of episode c_epi: the draw reset_lane_sampled would make
+                Rng g(reset_seed, d.idx0 + (uint32_t)i, RNG_INIT, (uint64_t)c_epi);
+                float init[E::I];
+                E::sample_init(T, c, g, init);
+#pragma unroll
+                for (int j = 0; j < E::I; ++j) l_stock[j * NE + le] = init[j];
+                if (REC && E::TRIG > 0) {
+                    float s0[E::S], tr0[NT];
+                    E::state_from_init(init, s0);
+                    E::observe_p(s0, tr0);
+#pragma unroll
+                    for (int j = 0; j < E::TRIG; ++j) l_stock[(E::I + j) * NE + le] = tr0[j];
+                }
+                __hip_atomic_store(&l_stag[le], c_epi, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                c_tag = c_epi;
+            }
+        };
         if (!DP) carry = Rng::philox(seed, d.idx0 + (uint32_t)i, RNG_ACT, blk0);
         auto draw = [&](int bb) __attribute__((always_inline)) {
             if (DP) return;
@@ -1114,6 +1175,7 @@ __global__ __launch_bounds__(2 * NE) void k_rollout_ws(Task T, Dev d, int k_step
                             ret = 0.f;
                             yielded = false;
                             len = 0;
+                            c_epi += 1u;
                         }
                     }
                 }
@@ -1136,6 +1198,7 @@ __global__ __launch_bounds__(2 * NE) void k_rollout_ws(Task T, Dev d, int k_step
         };
         __builtin_amdgcn_s_waitcnt(0x0F70);
         draw(0);
+        refill();  // every lane's first entry: one full-wave pass per launch
         ws_barrier();
 #ifdef VS_WS_NOC  // diagnostic: the C wave only keeps the barriers
         for (int b = 0; b < nb; ++b) ws_barrier();
@@ -1149,6 +1212,7 @@ __global__ __launch_bounds__(2 * NE) void k_rollout_ws(Task T, Dev d, int k_step
             if (b >= 1) work(b - 1);  // reads l_act[(b - 1) & 1] before draw(b + 1) overwrites the same buffer
             VS_STAMP(st1);
             if (b + 1 < nb) draw(b + 1);
+            if ((b & (WS_REFILL - 1)) == WS_REFILL - 1) refill();
             VS_STAMP(st2);
             ws_barrier();
 #ifdef VS_WS_STAMP
@@ -1356,6 +1420,7 @@ struct vs_env {
     size_t stage_bytes = 0;
     void* stage_mask = nullptr;
     unsigned long long* d_counter = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;  // vs_timer_start / vs_timer_stop
 };
 
 namespace vs {

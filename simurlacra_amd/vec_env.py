@@ -579,6 +579,16 @@ class VecSimEnv:
         if n > 0:
             raise ValueErr(msg=f"At least one value is NaN! ({n} environment(s) flagged)")
 
+    def timer_start(self):
+        """HIP-event stopwatch on the handle's stream (vs_timer_start / vs_timer_stop)"""
+        self._check(self._lib.vs_timer_start(self._h), "vs_timer_start")
+
+    def timer_stop(self):
+        """device time [ms] of the launches issued since timer_start (waits for them)"""
+        ms = C.c_float()
+        self._check(self._lib.vs_timer_stop(self._h, C.byref(ms)), "vs_timer_stop")
+        return float(ms.value)
+
     def time_step_kernel(self, iters=100, actions=None, k_steps=1, record=False):
         """Average device time [ms] per launch of the step kernel (hipEvents on the kernel's stream)."""
         if record and k_steps > self._traj_cap:

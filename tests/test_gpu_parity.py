@@ -977,8 +977,8 @@ def test_step_jacobians_against_the_forks_autograd(vs, golden_dir):
 
 def test_headline_launch_values_at_65536(vs):
     """The exact launch bench.py times -- 65 536 QQubeSwingUpSim envs, per-env constants, auto-reset, every step recorded,
-    100 steps per launch, k_rollout_ws in 256-env workgroups on every compute unit -- checked for VALUES: records, final
-    buffers and episode statistics equal the plain kernel's bit for bit (and the 64-env shape's), 512 lanes of the last
+    100 steps per launch, k_rollout_ws in 64-env workgroups (four per compute unit) -- checked for VALUES: records, final
+    buffers and episode statistics equal the plain kernel's bit for bit (and the 256-env shape's), 512 lanes of the last
     recorded step are re-stepped by the fp64 oracle, and the record planes hold what rollout() keeps (mode 2)."""
     L = vs._lib
     n, T = 65536, 100
@@ -997,7 +997,7 @@ def test_headline_launch_values_at_65536(vs):
         e.step_random(T, seed=3, record=True)  # rows 100 .. 199: a second launch continues the streams
         trio[variant] = e
     auto = vs.VecSimEnv("qq-su", n, **KW["qq-su"])
-    assert auto.rollout_variant() == "k_rollout_ws"  # what the automatic choice launches at this size
+    assert auto.rollout_variant() == "k_rollout_ws64"  # what the automatic choice (and bench.py) launches at this size
     auto.close()
     a = trio["k_rollout"]
     tt_a = a.traj_tensors(2 * T)
@@ -1036,9 +1036,9 @@ def test_rollout_variant_selection(vs):
     faster shape at 256 -- and never with a wrapper pipeline, the state-and-time dependent final reward, or live
     randomisation of constants its reward wave reads"""
     e = vs.VecSimEnv("qq-su", 65536, **KW["qq-su"])
-    assert e.rollout_variant() == "k_rollout_ws"
+    assert e.rollout_variant() == "k_rollout_ws64"
     e.set_randomizer([("gravity_const", "normal", 9.81, 1.0, 1e-4, np.inf)])
-    assert e.rollout_variant() == "k_rollout_ws64"  # a redraw stalls one pair of waves instead of four
+    assert e.rollout_variant() == "k_rollout_ws64"  # (a redraw stalls one pair of waves instead of four)
     e.set_rollout_variant("k_rollout_ws")
     assert e.rollout_variant() == "k_rollout_ws"
     e.set_rollout_variant(None)
@@ -1056,16 +1056,19 @@ def test_rollout_variant_selection(vs):
     e.set_rollout_variant("k_rollout_ws")
     assert e.rollout_variant() == "k_rollout"  # the pipeline still wins over the pin
     e.set_act_pipeline(delay=0)
-    assert e.rollout_variant() == "k_rollout_ws"
+    assert e.rollout_variant() == "k_rollout_ws"  # the pin holds again
+    e.set_rollout_variant(None)
+    assert e.rollout_variant() == "k_rollout_ws64"
     e.close()
     for n_big, expect in ((65537, "k_rollout_ws64"), (98304, "k_rollout_ws64"), (98305, "k_rollout"), (131072, "k_rollout")):
         big = vs.VecSimEnv("qq-su", n_big, **KW["qq-su"])
         assert big.rollout_variant() == expect, n_big
         big.close()
     for name, n, expect in (("omo", 4096, "k_rollout_ws64"), ("qbb", 4096, "k_rollout_ws64"), ("qbb", 32768, "k_rollout_ws64"),
-                            ("qbb", 65536, "k_rollout"), ("qcp-st", 4096, "k_rollout"), ("bob", 65536, "k_rollout_ws64"),
-                            ("bob", 98304, "k_rollout_ws64"), ("qcp-su", 65536, "k_rollout_ws"), ("qcp-su", 98304, "k_rollout"),
-                            ("qq-su", 4096, "k_rollout_ws64"), ("qq-su", 32768, "k_rollout_ws")):
+                            ("qbb", 65536, "k_rollout"), ("qcp-st", 4096, "k_rollout"), ("bob", 65536, "k_rollout_ws"),
+                            ("bob-d", 65536, "k_rollout_ws64"), ("bob", 98304, "k_rollout_ws64"), ("qcp-su", 65536, "k_rollout_ws"),
+                            ("qcp-su", 98304, "k_rollout"), ("qq-su", 4096, "k_rollout_ws64"), ("qq-su", 32768, "k_rollout_ws64"),
+                            ("omo", 65536, "k_rollout_ws64")):
         x = vs.VecSimEnv(name, n, **KW[name])
         assert x.rollout_variant() == expect, (name, n)
         x.set_rollout_variant("k_rollout_ws")
