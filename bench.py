@@ -494,8 +494,8 @@ def roofline(args, env, local_rank, d, n, chunk, ms_region=None):
             roof["traffic"], roof["traffic_source"] = tab[key]["traffic_bytes_per_launch"], os.path.basename(tf)
     except Exception:
         pass
-    if args.no_extras:
-        return roof
+    if args.no_extras or int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        return roof  # the reference points and the extra legs are measured at N = 1 only: the other ranks would wait
     # the practical HBM ceiling next to the nominal one -- in-repo float4 copy / fill kernels (1 GiB per pass,
     # far beyond the caches, 4 independent 16-B accesses per thread, non-temporal), timed with HIP events
     g = ctypes.c_float()

@@ -964,9 +964,6 @@ __global__ __launch_bounds__(2 * NE) void k_rollout_ws(Task T, Dev d, int k_step
                             an[j] = vsel(nrm, m, a[j]);
                         }
                     }
-                    bool err = false;
-#pragma unroll
-                    for (int j = 0; j < E::A; ++j) err |= visnan(an[j]);
                     E::limit_act(c, alo, ahi, an, ac);
                     E::dynamics(T, c, s, h, ac, (REC && E::TRIG > 0) ? (const float*)tr : (const float*)nullptr);
                     // the trig of the new state right behind the dynamics, in the same basic block as the bounds test and the
@@ -978,12 +975,13 @@ __global__ __launch_bounds__(2 * NE) void k_rollout_ws(Task T, Dev d, int k_step
                     failed = false;
 #pragma unroll
                     for (int j = 0; j < E::S; ++j) {
-                        err |= isnan(s[j]);
                         if (!E::SYMMETRIC_BOX) failed |= (s[j] < slo[j]) | (s[j] > shi[j]);
                     }
                     if (E::SYMMETRIC_BOX) failed = outside_symmetric_box<E::S>(s, shi);
                     done = failed | (step >= T.max_steps);
-                    err_acc |= err;
+                    // No per-step NaN test on this wave: a NaN action (clip and dead zone keep it) or state makes the state NaN
+                    // in every family, a NaN state is inside no box test (never `failed`) and stays NaN until the lane is reset
+                    // by its time-out or the launch ends -- the two places where the sticky flag is raised below.
                     fin = done && valid;
                 }
                 unsigned fl = (done ? WSF_DONE : 0u) | (E::FINAL != FINAL_NONE && failed ? WSF_FAILED : 0u) |
@@ -994,6 +992,8 @@ __global__ __launch_bounds__(2 * NE) void k_rollout_ws(Task T, Dev d, int k_step
                 if (AR) {
                     if (__builtin_amdgcn_ballot_w64(fin) != 0ull) {
                         if (fin) {
+#pragma unroll
+                            for (int j = 0; j < E::S; ++j) err_acc |= isnan(s[j]);
                             load_consts<E, UNI>(d, i, c, E::KS, E::K);
                             bool stocked = false;
                             if (STOCK) {
@@ -1052,6 +1052,8 @@ __global__ __launch_bounds__(2 * NE) void k_rollout_ws(Task T, Dev d, int k_step
             q[0] = acc0, q[1] = acc1, q[2] = acc2, q[3] = (unsigned long long)nb;
         }
 #endif
+#pragma unroll
+        for (int j = 0; j < E::S; ++j) err_acc |= isnan(s[j]);
         if (err_acc && valid) d.err[i] = 1;
         E::observe(s, ob);
 #pragma unroll

@@ -279,9 +279,17 @@ class VecSimPyEnv(SimEnv):
         init = init_state.reshape(1, -1) if init_state.ndim == 1 else init_state
         if init.shape[0] != self._num_envs or init.shape[1] not in (v.dims["I"], v.dims["S"]):
             raise ShapeErr(given=init_state, expected_match=self.init_space)
-        if init.shape[1] != v.dims["S"] or v.dims["I"] == v.dims["S"]:
-            # element of the init space: non-fatal containment check, only prints (pysim/base.py:189-193)
-            pass
+        if init.shape[1] != v.dims["S"]:
+            # an element of the init space (a state-shaped one is copied verbatim, unchecked: pysim/base.py:184-188):
+            # non-fatal containment check -- the reference only prints (pysim/base.py:189-193)
+            for row in init:
+                try:
+                    inside = self.init_space.contains(np.asarray(row, dtype=np.float64))
+                except Exception:  # (NaN / shape errors surface in the step, as in the reference)
+                    inside = True
+                if not inside:
+                    print("The  init state is not within init state space.")
+                    break
         v.reset(init_state=init.astype(np.float32))
         obs = v.get(L.VS_OBS).astype(np.float64)
         state = v.get(L.VS_STATE).astype(np.float64)

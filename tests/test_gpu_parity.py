@@ -613,6 +613,7 @@ def test_mixed_batch_equals_separate_handles(vs, auto_reset):
         for e in (a, b):
             e.set_params(np.tile(vs.nominal_params(e.name), (e.n_envs, 1)))
             e.set_auto_reset(auto_reset, seed=21)
+            e.set_record_mode(2 if auto_reset else 1)  # the mixed launch records in the members' mode
             e.reset(seed=5)
     mixed.step_random(150, seed=9, record=True)
     for b in solo:
@@ -1176,3 +1177,64 @@ def test_fused_kernels_fuzz_against_step_kernel(vs):
         for e in [ref, *envs.values()]:
             assert e.error_count() == 0
             e.close()
+
+
+def test_freeze_done_and_event_timer(vs):
+    """vs_set_freeze_done: with it on, vs_step leaves finished lanes alone (state, observation, counters, flags; reward 0;
+    a NaN fed to such a lane raises no flag) -- rollout() stops at done -- and off (default) env.step() keeps stepping as in
+    the reference; vs_timer_start / vs_timer_stop bracket launches on the handle's stream"""
+    L = vs._lib
+    n = 512
+    kw = dict(KW["bob"], max_steps=6)
+    a, b = vs.VecSimEnv("bob", n, **kw), vs.VecSimEnv("bob", n, **kw)
+    a.set_freeze_done(True)
+    for e in (a, b):
+        e.reset(seed=3)
+    rng = np.random.default_rng(0)
+    for t in range(6):
+        act = dev(rng.uniform(-20, 20, (n, 1)))
+        a.step(act), b.step(act)
+    assert a.get(L.VS_DONE).all() and np.array_equal(a.get(L.VS_STATE), b.get(L.VS_STATE))  # time-out at step 6 for everyone
+    frozen = {w: a.get(w).copy() for w in (L.VS_STATE, L.VS_OBS, L.VS_STEPCOUNT, L.VS_DONE, L.VS_RETURNS)}
+    bad = dev(np.full((n, 1), np.nan))
+    a.timer_start()
+    a.step(bad), b.step(bad)
+    ms = a.timer_stop()
+    assert 0.0 < ms < 50.0
+    for w, v in frozen.items():
+        assert np.array_equal(a.get(w), v), w
+    assert (a.get(L.VS_REW) == 0).all() and a.error_count() == 0
+    assert b.error_count() == n and (b.get(L.VS_STEPCOUNT) == 7).all()  # the unfrozen handle stepped on and saw the NaN
+    a.set_freeze_done(False)
+    a.step(dev(np.zeros((n, 1))))
+    assert (a.get(L.VS_STEPCOUNT) == 7).all()
+    a.close(), b.close()
+
+
+@pytest.mark.parametrize("auto_reset", [False, True])
+def test_nan_flag_is_the_same_in_every_fused_kernel(vs, auto_reset):
+    """a lane whose state turns NaN (here: a NaN domain parameter) raises the sticky error flag in k_rollout (tested per
+    step) and in both shapes of k_rollout_ws (tested where a NaN state must surface: at the lane's time-out reset and at
+    the end of the launch) -- the same lanes, nothing else"""
+    L = vs._lib
+    n = 700
+    flags = {}
+    for variant in ("k_rollout", "k_rollout_ws", "k_rollout_ws64"):
+        e = vs.VecSimEnv("qq-su", n, **dict(KW["qq-su"], max_steps=20))
+        P = np.tile(vs.nominal_params("qq-su"), (n, 1))
+        P[[5, 64, 699], 0] = np.nan
+        e.set_params(P)
+        e.set_rollout_variant(variant)
+        e.set_auto_reset(auto_reset, seed=3)
+        e.reset(seed=4)
+        e.set_traj_capacity(30)
+        e.step_random(30, seed=5, record=True)  # crosses the time-out at step 20
+        flags[variant] = e.get(L.VS_ERRFLAG).copy()
+        assert e.error_count() == 3
+        with pytest.raises(vs.ValueErr):
+            e.raise_on_error()
+        e.close()
+    expect = np.zeros(n, dtype=np.uint8)
+    expect[[5, 64, 699]] = 1
+    for variant, f in flags.items():
+        assert np.array_equal(f, expect), variant
