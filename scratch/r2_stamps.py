@@ -11,8 +11,13 @@ sys.path.insert(0, ROOT)
 import simurlacra_amd as vs  # noqa: E402
 from bench import ENV_KW  # noqa: E402
 
-for name, n, var, rec in (("qq-su", 65536, "k_rollout_ws", 1), ("qq-su", 65536, "k_rollout_ws", 0), ("qq-su", 65536, "k_rollout_ws64", 1),
-                          ("qq-su", 4096, "k_rollout_ws64", 1), ("qq-su", 4096, "k_rollout_ws64", 0), ("qcp-su", 65536, "k_rollout_ws", 1)):
+CASES = (("qq-su", 65536, "k_rollout_ws", 1), ("qq-su", 65536, "k_rollout_ws", 0), ("qq-su", 65536, "k_rollout_ws64", 1),
+         ("qq-su", 4096, "k_rollout_ws64", 1), ("qq-su", 4096, "k_rollout_ws64", 0), ("qcp-su", 65536, "k_rollout_ws", 1),
+         ("qbb", 32768, "k_rollout_ws64", 1), ("qbb", 32768, "k_rollout_ws64", 0), ("bob", 65536, "k_rollout_ws", 1),
+         ("omo", 65536, "k_rollout_ws64", 1))
+if len(sys.argv) > 1:
+    CASES = tuple(c for c in CASES if c[0] in sys.argv[1:])
+for name, n, var, rec in CASES:
     env = vs.VecSimEnv(name, n, **ENV_KW[name])
     env.set_params(np.tile(vs.nominal_params(name), (n, 1)))
     env.set_auto_reset(True, seed=1)

@@ -253,6 +253,7 @@ struct Omo : EnvDefaults<1> {
     static constexpr int S = 2, A = 1, O = 2, H = 0, I = 2, P = 3, K = 4, KS = 4;
     static constexpr int REW = REW_QUADR, RADIAL = -1, CMAX = -1;
     static constexpr int FINAL = FINAL_CONST_MALUS;  // FinalRewTask(factor 1e3, always_negative), :75-79
+    static constexpr bool WS_DRAW_P = true;  // a two-instruction physics step: the reward / record wave is the long one
     // (WS_PAYS: with its batch loops unrolled the split pays even for this small step: +8 % with records, +5 % without)
     enum { C_A10, C_A11, C_B1, C_AMAX };
     __device__ static void calc_consts(const Task&, const float* p, float* c) {  // _calc_constants :88-103
@@ -618,6 +619,7 @@ struct Pend : EnvDefaults<1> {
     static constexpr int S = 2, A = 1, O = 3, H = 0, I = 2, P = 5, K = 4, KS = 4;
     // idcs=[1] in the reference (pendulum.py:87): the 2pi modulo is applied to the theta_dot error
     static constexpr int REW = REW_EXP, RADIAL = 1, CMAX = -1;
+    static constexpr bool WS_DRAW_P = true;
     enum { C_MGL2, C_DAMP, C_INV_J, C_AMAX };
     __device__ static void calc_consts(const Task&, const float* p, float* c) {
         float g = p[0], m = p[1], l = p[2];
@@ -747,9 +749,14 @@ struct Qbb : EnvDefaults<2> {
         R th_y_ddot = (c[C_AM] * a1 - c[C_BEQV] * th_y_dot) * c[C_JEQ];
         R sx, cx, sy, cy, sa, ca, sb, cb;
         sincos_fast(th_x, &sx, &cx);
-        sincos_fast(th_y, &sy, &cy);
         sincos_fast(h[0], &sa, &ca);
+#ifdef VS_QBB_HALF  // diagnostic builds only: what ONE axis of the ball balancer costs (results are wrong)
+        sy = sx, cy = cx, sb = sa, cb = ca;
+        th_y_dot = th_x_dot, y = x, y_dot = x_dot, a1 = a0;
+#else
+        sincos_fast(th_y, &sy, &cy);
         sincos_fast(h[1], &sb, &cb);
+#endif
         R ck = c[C_CKIN];
         R inv_ca = rcp_fast(ca), inv_cb = rcp_fast(cb);
         R a_dot = ck * th_x_dot * cx * inv_ca;

@@ -840,7 +840,9 @@ __global__ __launch_bounds__(2 * NE) void k_rollout_ws(Task T, Dev d, int k_step
                                                        uint64_t epoch0) {
     static_assert(E::FINAL != FINAL_STATE_TIME, "needs the post-step state on the reward side");
     static_assert(NE == 64 || NE == 128 || NE == 256, "envs per workgroup");
-    static_assert(!DP || !E::REWARD_SIDE_USES_CONSTS, "a batch of actions is drawn ahead: the action bounds must not change at a reset");
+    // DP draws a batch of actions ahead with the action bounds of that moment: fine, because the bounds change only with a
+    // redraw of the domain parameters at a reset, and a family whose bounds depend on them (REWARD_SIDE_USES_CONSTS) never
+    // runs this kernel under live randomisation (Launch<E>::variant)
     constexpr int HM = REC == 2 ? E::H : 0;                      // hidden state travels for the full records only
     constexpr int AM = DP ? E::A : 0;                            // the action travels in the message when P draws it
     constexpr int M0 = E::S + (REC ? E::TRIG : 0) + HM + AM + 1;  // message of one step
