@@ -235,6 +235,14 @@ int vs_set_auto_reset(vs_handle h, int on, uint64_t seed);
 /* actions: device f32, element (env i, dim j) at actions[i * env_stride + j * dim_stride]
  * ([A][ld] SoA: env_stride 1, dim_stride ld;  [N][A] row-major policy output: env_stride A, dim_stride 1) */
 int vs_step(vs_handle h, const float* actions, int64_t env_stride, int64_t dim_stride);
+/* vs_step that also records the step (policy in the loop: rollout() with the caller's policy, rollout.py:185-258): the
+ * observation the policy saw (VS_OBS as the previous step / the reset left it), its action, the reward and the done bit --
+ * in record mode 2 also the state and hidden state before the step and env.limit_act(act) -- go into row `row` of the
+ * VS_TRAJ_* buffers (same layout as the records of vs_step_random).  row < 0: the row comes from a device-side counter of
+ * the handle (vs_set_record_row), which a one-thread kernel behind the step advances -- nothing host-side enters the
+ * launch, so a captured hipGraph of (policy, vs_step_record) pairs replays correctly.  Rows beyond the capacity are skipped. */
+int vs_step_record(vs_handle h, const float* actions, int64_t env_stride, int64_t dim_stride, int row);
+int vs_set_record_row(vs_handle h, int row);
 /* vs_step plus the step Jacobians d(s', r, obs') / d(s, a) (forward-mode differentiation of the same step code): what the
  * fork computes with torch autograd for its SAC-with-gradients (P/sampling/rollout.py:836-837 around
  * quanser_cartpole.py:233-431), for every family.  The raw action is the differentiation variable (a clipped or dead-zoned

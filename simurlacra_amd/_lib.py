@@ -58,6 +58,8 @@ _SIGNATURES = {
     "vs_set_auto_reset": (C.c_int, [_P, C.c_int, C.c_uint64]),
     "vs_step": (C.c_int, [_P, _P, C.c_int64, C.c_int64]),
     "vs_step_jac": (C.c_int, [_P, _P, C.c_int64, C.c_int64]),
+    "vs_step_record": (C.c_int, [_P, _P, C.c_int64, C.c_int64, C.c_int]),
+    "vs_set_record_row": (C.c_int, [_P, C.c_int]),
     "vs_step_random": (C.c_int, [_P, C.c_uint64, C.c_int, C.c_int]),
     "vs_seek_random": (C.c_int, [_P, C.c_uint64]),
     "vs_rollout_variant": (C.c_int, [_P]),

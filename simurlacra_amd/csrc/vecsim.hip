@@ -4,6 +4,8 @@
 
 namespace vs {
 
+__global__ void k_bump_row(int* row) { *row += 1; }
+
 __global__ void k_count_err(const uint8_t* err, int n, unsigned long long* out) {
     int i = blockIdx.x * BLOCK + threadIdx.x;
     bool e = i < n && err[i] != 0;
@@ -377,6 +379,7 @@ int vs_create(int env_type, int64_t n_envs, double dt, int64_t max_steps, int de
     CK(dalloc(h, &d.ep_env, (size_t)d.ep_cap));
     CK(dalloc(h, &d.ep_count, (size_t)1));
     CK(dalloc(h, &h->d_counter, (size_t)1));
+    CK(dalloc(h, &d.rec_row, (size_t)1));
 #ifdef VS_WS_STAMP
     CK(dalloc(h, &d.dbg, (size_t)(ld / 64) * 8));
 #endif
@@ -634,6 +637,30 @@ int vs_step(vs_handle h, const float* actions, int64_t env_stride, int64_t dim_s
     return VS_OK;
 }
 
+int vs_step_record(vs_handle h, const float* actions, int64_t env_stride, int64_t dim_stride, int row) {
+    if (!h || !actions) return fail(h, VS_ERR_ARG, "vs_step_record: NULL argument");
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(h->stream, &st) != hipSuccess) (void)hipGetLastError();
+    if (st == hipStreamCaptureStatusNone) {
+        if (!is_device_ptr(actions)) return fail(h, VS_ERR_ARG, "vs_step_record: actions must be device memory");
+        HIPCHK(h, hipSetDevice(h->device));
+    }
+    if (h->traj_cap <= 0) return fail(h, VS_ERR_STATE, "vs_step_record: set the record capacity first (vs_set_traj_capacity)");
+    if (row >= h->traj_cap) return fail(h, VS_ERR_STATE, "vs_step_record: row exceeds vs_set_traj_capacity");
+    DISPATCH_ENV(h->type, Launch<E>::step(h, actions, (long)env_stride, (long)dim_stride, h->record_mode, row < 0 ? -1 : row));
+    if (row < 0) hipLaunchKernelGGL(k_bump_row, dim3(1), dim3(1), 0, h->stream, h->d.rec_row);
+    HIPCHK(h, hipGetLastError());
+    return VS_OK;
+}
+
+int vs_set_record_row(vs_handle h, int row) {
+    if (!h || row < 0) return fail(h, VS_ERR_ARG, "vs_set_record_row: bad argument");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpyAsync(h->d.rec_row, &row, sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));  // `row` lives on this stack frame
+    return VS_OK;
+}
+
 int vs_seek_random(vs_handle h, uint64_t step_index) {
     if (!h) return VS_ERR_ARG;
     h->epoch = step_index;
@@ -673,6 +700,7 @@ static int free_traj(vs_handle h) {
     d.traj_rec = nullptr;
     d.traj_done = nullptr;
     h->traj_cap = 0;
+    d.traj_rows = 0;
     return VS_OK;
 }
 
@@ -688,6 +716,7 @@ int vs_set_traj_capacity(vs_handle h, int t_max) {
     if ((rc = dalloc(h, &d.traj_rec, (size_t)t_max * record_width(h->type, h->record_mode) * ld))) return rc;
     if ((rc = dalloc(h, &d.traj_done, (size_t)((t_max + 31) / 32) * ld))) return rc;
     h->traj_cap = t_max;
+    d.traj_rows = t_max;
     return VS_OK;
 }
 

@@ -89,6 +89,8 @@ struct Dev {
     float* traj_rec;     // packed per-step records, see store_record
     uint32_t* traj_done; // done flags of the recorded steps, one BIT per env and step: word [t / 32][env], bit t % 32
     int traj_t0;  // record row offset of the next recording vs_step_random
+    int traj_rows;  // capacity of the record buffers in rows
+    int* rec_row;   // device-side row counter of vs_step_record(row < 0), advanced by k_bump_row
     float *jac_s, *jac_r, *jac_o;  // step Jacobians (vs_step_jac), allocated on first use
     unsigned long long* dbg;       // diagnostic builds only (-DVS_WS_STAMP): per-wave cycle sums, [ld / 64][2 roles][4]
     int n, ld;
@@ -405,158 +407,6 @@ __device__ __forceinline__ void auto_reset(const Task& T, const Dev& d, bool fin
     }
 }
 
-// ------------------------------------------------------------------------------------------------------- step kernel
-// vs_step: one fused SimPyEnv.step per lane.  AR = auto-reset of finished lanes inside the same launch.
-// No host-side counter enters the kernel: replaying a captured hipGraph of vs_step launches is safe.
-// PIPE: the wrapper pipeline (struct Pipe) is compiled in; the default kernels do not carry it.
-template <class E, bool UNI, bool AR, bool PIPE = false>
-__device__ __forceinline__ void step_body(const Task& T, const Dev& d, const float* __restrict__ act, long env_stride,
-                                          long dim_stride, uint64_t seed, int block) {
-    int i = block * BLOCK + threadIdx.x;
-    if (i >= d.ld) return;
-    const size_t ld = d.ld;
-    float c[E::K], s[E::S], h[E::H > 0 ? E::H : 1], a[E::A];
-    load_consts<E, UNI>(d, i, c, 0, E::KS);
-#pragma unroll
-    for (int j = 0; j < E::S; ++j) s[j] = d.state[j * ld + i];
-#pragma unroll
-    for (int j = 0; j < E::H; ++j) h[j] = d.hidden[j * ld + i];
-    bool valid = i < d.n;
-#pragma unroll
-    for (int j = 0; j < E::A; ++j) a[j] = valid ? act[(size_t)i * env_stride + (size_t)j * dim_stride] : 0.f;
-    int step = d.step[i];
-    bool yielded = E::FINAL != FINAL_NONE ? d.yielded[i] != 0 : false;
-    const bool noisy = PIPE && (d.pipe.act_noise | d.pipe.obs_noise);  // wave-uniform
-    uint32_t epi = noisy ? d.ep_idx[i] : 0u;
-    if (!AR && (T.flags & VS_FLAG_FREEZE_DONE)) {  // wave-uniform flag
-        // rollout() stops at done (rollout.py:185): a lane whose episode has ended keeps its state, observation, step
-        // counter and done flag; its reward reads 0 and nothing it is fed can raise the NaN flag
-        if (d.done[i] != 0) {
-            d.rew[i] = 0.f;
-            return;
-        }
-    }
-
-    StepOut o = step_one<E, float>(T, c, s, h, a, step, yielded, (const float*)nullptr, PIPE ? &d : (const Dev*)nullptr,
-                                   i, epi);
-
-    float ret = d.ret[i] + o.rew;
-    d.rew[i] = o.rew;
-    d.done[i] = o.done;
-    d.failed[i] = o.failed;
-    if (o.err && valid) d.err[i] = 1;  // sticky, write-only
-
-    if (AR) {
-        bool fin = o.done && valid;
-        if (__builtin_amdgcn_ballot_w64(fin) != 0ull) {  // single-step kernel: the per-env counters are touched by finishing lanes only
-            EpStat es{0u, 0u, 0.f, 0};
-            if (fin) es = EpStat{d.ep_idx[i], d.es_count[i], d.es_retsum[i], d.es_lensum[i]};
-            auto_reset<E, UNI>(T, d, fin, i, seed, c, s, h, step, ret, yielded, es);
-            if (fin) {
-                d.ep_idx[i] = es.epi;
-                d.es_count[i] = es.count;
-                d.es_retsum[i] = es.retsum;
-                d.es_lensum[i] = es.lensum;
-            }
-        }
-    }
-
-    float ob[E::O];
-    E::observe(s, ob);
-    if (PIPE && d.pipe.obs_on) {
-        if (AR && noisy) epi = d.ep_idx[i];  // a lane that was just reset shows the first observation of its new episode
-        pipe_obs<E>(d, i, epi, step, ob, ob);
-    }
-#pragma unroll
-    for (int j = 0; j < E::S; ++j) d.state[j * ld + i] = s[j];
-#pragma unroll
-    for (int j = 0; j < E::H; ++j) d.hidden[j * ld + i] = h[j];
-#pragma unroll
-    for (int j = 0; j < E::O; ++j) d.obs[j * ld + i] = ob[j];
-    d.step[i] = step;
-    d.ret[i] = ret;
-    if (E::FINAL != FINAL_NONE) d.yielded[i] = yielded;
-}
-
-template <class E, bool UNI, bool AR, bool PIPE>
-__global__ __launch_bounds__(BLOCK) void k_step(Task T, Dev d, const float* __restrict__ act, long env_stride,
-                                                long dim_stride, uint64_t seed) {
-    step_body<E, UNI, AR, PIPE>(T, d, act, env_stride, dim_stride, seed, (int)blockIdx.x);
-}
-
-// ---------------------------------------------------------------------------------------------------- Jacobian kernel
-// vs_step_jac: vs_step plus d(s', r, obs') / d(s, a) by forward-mode differentiation of the very same step code
-// (Dual<S+A> instead of float, vecsim_dual.h).  What the fork obtains with torch autograd around its re-implemented
-// QCartPole dynamics (P/sampling/rollout.py:836-837, quanser_cartpole.py:233-431) -- here for every family.
-// Input x = (s_0 .. s_{S-1}, a_0 .. a_{A-1}); the hidden state (qcp th_ddot, qbb plate angles) is held constant.
-// Layouts: jac_s [S][S+A][ld], jac_r [S+A][ld], jac_o [O][S+A][ld].  The step values come from the float path and are
-// bit-identical to vs_step.
-template <class E, bool UNI>
-__global__ __launch_bounds__(BLOCK) void k_step_jac(Task T, Dev d, const float* __restrict__ act, long env_stride,
-                                                    long dim_stride) {
-    int i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= d.ld) return;
-    constexpr int NI = E::S + E::A;
-    using D = Dual<NI>;
-    const size_t ld = d.ld;
-    float c[E::K];
-    load_consts<E, UNI>(d, i, c, 0, E::KS);
-    D s[E::S], h[E::H > 0 ? E::H : 1], a[E::A], ob[E::O];
-    bool valid = i < d.n;
-#pragma unroll
-    for (int j = 0; j < E::S; ++j) {
-        s[j] = D(d.state[j * ld + i]);
-        s[j].d[j] = 1.f;
-    }
-#pragma unroll
-    for (int j = 0; j < E::H; ++j) h[j] = D(d.hidden[j * ld + i]);
-#pragma unroll
-    for (int j = 0; j < E::A; ++j) {
-        a[j] = D(valid ? act[(size_t)i * env_stride + (size_t)j * dim_stride] : 0.f);
-        a[j].d[E::S + j] = 1.f;
-    }
-    int step = d.step[i];
-    bool yielded = E::FINAL != FINAL_NONE ? d.yielded[i] != 0 : false;
-    // values: the float path, so that they are bit-identical to vs_step (operator-by-operator dual arithmetic cannot
-    // reproduce the FMA contraction of the float expressions); tangents: the dual path on the same inputs
-    float sf[E::S], hf[E::H > 0 ? E::H : 1], af[E::A], obf[E::O];
-#pragma unroll
-    for (int j = 0; j < E::S; ++j) sf[j] = s[j].v;
-#pragma unroll
-    for (int j = 0; j < E::H; ++j) hf[j] = h[j].v;
-#pragma unroll
-    for (int j = 0; j < E::A; ++j) af[j] = a[j].v;
-    int step_d = step;
-    bool yielded_d = yielded;
-    StepOut of = step_one<E, float>(T, c, sf, hf, af, step, yielded, (const float*)nullptr);
-    E::observe(sf, obf);
-    StepOutT<D> o = step_one<E, D>(T, c, s, h, a, step_d, yielded_d, (const D*)nullptr);
-    E::observe(s, ob);
-    d.ret[i] = d.ret[i] + of.rew;
-    d.rew[i] = of.rew;
-    d.done[i] = of.done;
-    d.failed[i] = of.failed;
-    if (of.err && valid) d.err[i] = 1;
-#pragma unroll
-    for (int j = 0; j < E::S; ++j) {
-        d.state[j * ld + i] = sf[j];
-#pragma unroll
-        for (int k = 0; k < NI; ++k) d.jac_s[((size_t)j * NI + k) * ld + i] = s[j].d[k];
-    }
-#pragma unroll
-    for (int j = 0; j < E::H; ++j) d.hidden[j * ld + i] = hf[j];
-#pragma unroll
-    for (int j = 0; j < E::O; ++j) {
-        d.obs[j * ld + i] = obf[j];
-#pragma unroll
-        for (int k = 0; k < NI; ++k) d.jac_o[((size_t)j * NI + k) * ld + i] = ob[j].d[k];
-    }
-#pragma unroll
-    for (int k = 0; k < NI; ++k) d.jac_r[(size_t)k * ld + i] = o.rew.d[k];
-    d.step[i] = step;
-    if (E::FINAL != FINAL_NONE) d.yielded[i] = yielded;
-}
-
 // ---------------------------------------------------------------------------------------------------- step records
 // One env step is recorded as F = O + A + 1 floats  [obs (before the step) | action of the policy | reward].
 // A step's records are stored as planes of 4, 2 or 1 floats per env -- F = 4 * NQ + 2 * H2 + H1 -- each plane [ld][w]:
@@ -655,6 +505,186 @@ __device__ __forceinline__ void applied_action(const Task& T, const float* c, co
         hi[j] = nrm ? 1.0f : ahi[j];
     }
     E::limit_act(c, lo, hi, a, a_app);
+}
+
+// ------------------------------------------------------------------------------------------------------- step kernel
+// vs_step: one fused SimPyEnv.step per lane.  AR = auto-reset of finished lanes inside the same launch.
+// No host-side counter enters the kernel: replaying a captured hipGraph of vs_step launches is safe.
+// PIPE: the wrapper pipeline (struct Pipe) is compiled in; the default kernels do not carry it.
+// REC (vs_step_record): the step also writes its record -- what rollout() keeps of a step taken with the caller's policy
+// (rollout.py:237-258): the observation the policy saw (VS_OBS as the previous step / the reset left it), the policy's
+// action, the reward, and in mode 2 the state and hidden state before the step and env.limit_act(act) -- into row `row` of
+// the VS_TRAJ_* buffers, or, for row < 0, into the row the handle's device-side counter names (Dev::rec_row: a captured
+// hipGraph replays with the counter advanced by k_bump_row between the steps).  Rows beyond the capacity are not written.
+template <class E, bool UNI, bool AR, bool PIPE = false, int REC = 0>
+__device__ __forceinline__ void step_body(const Task& T, const Dev& d, const float* __restrict__ act, long env_stride,
+                                          long dim_stride, uint64_t seed, int block, int row = 0) {
+    int i = block * BLOCK + threadIdx.x;
+    if (i >= d.ld) return;
+    const size_t ld = d.ld;
+    float c[E::K], s[E::S], h[E::H > 0 ? E::H : 1], a[E::A];
+    load_consts<E, UNI>(d, i, c, 0, E::KS);
+#pragma unroll
+    for (int j = 0; j < E::S; ++j) s[j] = d.state[j * ld + i];
+#pragma unroll
+    for (int j = 0; j < E::H; ++j) h[j] = d.hidden[j * ld + i];
+    bool valid = i < d.n;
+#pragma unroll
+    for (int j = 0; j < E::A; ++j) a[j] = valid ? act[(size_t)i * env_stride + (size_t)j * dim_stride] : 0.f;
+    int step = d.step[i];
+    bool yielded = E::FINAL != FINAL_NONE ? d.yielded[i] != 0 : false;
+    const bool noisy = PIPE && (d.pipe.act_noise | d.pipe.obs_noise);  // wave-uniform
+    uint32_t epi = noisy ? d.ep_idx[i] : 0u;
+    if (!AR && (T.flags & VS_FLAG_FREEZE_DONE)) {  // wave-uniform flag
+        // rollout() stops at done (rollout.py:185): a lane whose episode has ended keeps its state, observation, step
+        // counter and done flag; its reward reads 0 and nothing it is fed can raise the NaN flag
+        if (d.done[i] != 0) {
+            d.rew[i] = 0.f;
+            return;
+        }
+    }
+    float ob_pre[E::O], s_pre[E::S], h_pre[E::H > 0 ? E::H : 1], a_app[E::A];
+    if (REC) {
+        if (row < 0) row = *d.rec_row;
+#pragma unroll
+        for (int j = 0; j < E::O; ++j) ob_pre[j] = d.obs[j * ld + i];
+    }
+    if (REC == 2) {
+#pragma unroll
+        for (int j = 0; j < E::S; ++j) s_pre[j] = s[j];
+#pragma unroll
+        for (int j = 0; j < E::H; ++j) h_pre[j] = h[j];
+        float alo[E::A], ahi[E::A];
+        E::act_bounds(c, alo, ahi);
+        applied_action<E>(T, c, alo, ahi, a, a_app);
+    }
+
+    StepOut o = step_one<E, float>(T, c, s, h, a, step, yielded, (const float*)nullptr, PIPE ? &d : (const Dev*)nullptr,
+                                   i, epi);
+    if (REC) {
+        if (row < d.traj_rows) {  // (wave-uniform)
+            store_record<E, REC>(d.traj_rec + (size_t)row * Rec<E, REC>::F * ld, ld, i, ob_pre, a, o.rew, s_pre, a_app, h_pre);
+            uint32_t* w = DoneBits::word(d, i, (size_t)row);  // one step per launch: complete the lane's word of this 32-row window
+            const uint32_t bit = 1u << ((unsigned)row & 31u);
+            *w = (*w & ~bit) | (o.done ? bit : 0u);
+        }
+    }
+
+    float ret = d.ret[i] + o.rew;
+    d.rew[i] = o.rew;
+    d.done[i] = o.done;
+    d.failed[i] = o.failed;
+    if (o.err && valid) d.err[i] = 1;  // sticky, write-only
+
+    if (AR) {
+        bool fin = o.done && valid;
+        if (__builtin_amdgcn_ballot_w64(fin) != 0ull) {  // single-step kernel: the per-env counters are touched by finishing lanes only
+            EpStat es{0u, 0u, 0.f, 0};
+            if (fin) es = EpStat{d.ep_idx[i], d.es_count[i], d.es_retsum[i], d.es_lensum[i]};
+            auto_reset<E, UNI>(T, d, fin, i, seed, c, s, h, step, ret, yielded, es);
+            if (fin) {
+                d.ep_idx[i] = es.epi;
+                d.es_count[i] = es.count;
+                d.es_retsum[i] = es.retsum;
+                d.es_lensum[i] = es.lensum;
+            }
+        }
+    }
+
+    float ob[E::O];
+    E::observe(s, ob);
+    if (PIPE && d.pipe.obs_on) {
+        if (AR && noisy) epi = d.ep_idx[i];  // a lane that was just reset shows the first observation of its new episode
+        pipe_obs<E>(d, i, epi, step, ob, ob);
+    }
+#pragma unroll
+    for (int j = 0; j < E::S; ++j) d.state[j * ld + i] = s[j];
+#pragma unroll
+    for (int j = 0; j < E::H; ++j) d.hidden[j * ld + i] = h[j];
+#pragma unroll
+    for (int j = 0; j < E::O; ++j) d.obs[j * ld + i] = ob[j];
+    d.step[i] = step;
+    d.ret[i] = ret;
+    if (E::FINAL != FINAL_NONE) d.yielded[i] = yielded;
+}
+
+template <class E, bool UNI, bool AR, bool PIPE, int REC>
+__global__ __launch_bounds__(BLOCK) void k_step(Task T, Dev d, const float* __restrict__ act, long env_stride,
+                                                long dim_stride, uint64_t seed, int row) {
+    step_body<E, UNI, AR, PIPE, REC>(T, d, act, env_stride, dim_stride, seed, (int)blockIdx.x, row);
+}
+
+// ---------------------------------------------------------------------------------------------------- Jacobian kernel
+// vs_step_jac: vs_step plus d(s', r, obs') / d(s, a) by forward-mode differentiation of the very same step code
+// (Dual<S+A> instead of float, vecsim_dual.h).  What the fork obtains with torch autograd around its re-implemented
+// QCartPole dynamics (P/sampling/rollout.py:836-837, quanser_cartpole.py:233-431) -- here for every family.
+// Input x = (s_0 .. s_{S-1}, a_0 .. a_{A-1}); the hidden state (qcp th_ddot, qbb plate angles) is held constant.
+// Layouts: jac_s [S][S+A][ld], jac_r [S+A][ld], jac_o [O][S+A][ld].  The step values come from the float path and are
+// bit-identical to vs_step.
+template <class E, bool UNI>
+__global__ __launch_bounds__(BLOCK) void k_step_jac(Task T, Dev d, const float* __restrict__ act, long env_stride,
+                                                    long dim_stride) {
+    int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= d.ld) return;
+    constexpr int NI = E::S + E::A;
+    using D = Dual<NI>;
+    const size_t ld = d.ld;
+    float c[E::K];
+    load_consts<E, UNI>(d, i, c, 0, E::KS);
+    D s[E::S], h[E::H > 0 ? E::H : 1], a[E::A], ob[E::O];
+    bool valid = i < d.n;
+#pragma unroll
+    for (int j = 0; j < E::S; ++j) {
+        s[j] = D(d.state[j * ld + i]);
+        s[j].d[j] = 1.f;
+    }
+#pragma unroll
+    for (int j = 0; j < E::H; ++j) h[j] = D(d.hidden[j * ld + i]);
+#pragma unroll
+    for (int j = 0; j < E::A; ++j) {
+        a[j] = D(valid ? act[(size_t)i * env_stride + (size_t)j * dim_stride] : 0.f);
+        a[j].d[E::S + j] = 1.f;
+    }
+    int step = d.step[i];
+    bool yielded = E::FINAL != FINAL_NONE ? d.yielded[i] != 0 : false;
+    // values: the float path, so that they are bit-identical to vs_step (operator-by-operator dual arithmetic cannot
+    // reproduce the FMA contraction of the float expressions); tangents: the dual path on the same inputs
+    float sf[E::S], hf[E::H > 0 ? E::H : 1], af[E::A], obf[E::O];
+#pragma unroll
+    for (int j = 0; j < E::S; ++j) sf[j] = s[j].v;
+#pragma unroll
+    for (int j = 0; j < E::H; ++j) hf[j] = h[j].v;
+#pragma unroll
+    for (int j = 0; j < E::A; ++j) af[j] = a[j].v;
+    int step_d = step;
+    bool yielded_d = yielded;
+    StepOut of = step_one<E, float>(T, c, sf, hf, af, step, yielded, (const float*)nullptr);
+    E::observe(sf, obf);
+    StepOutT<D> o = step_one<E, D>(T, c, s, h, a, step_d, yielded_d, (const D*)nullptr);
+    E::observe(s, ob);
+    d.ret[i] = d.ret[i] + of.rew;
+    d.rew[i] = of.rew;
+    d.done[i] = of.done;
+    d.failed[i] = of.failed;
+    if (of.err && valid) d.err[i] = 1;
+#pragma unroll
+    for (int j = 0; j < E::S; ++j) {
+        d.state[j * ld + i] = sf[j];
+#pragma unroll
+        for (int k = 0; k < NI; ++k) d.jac_s[((size_t)j * NI + k) * ld + i] = s[j].d[k];
+    }
+#pragma unroll
+    for (int j = 0; j < E::H; ++j) d.hidden[j * ld + i] = hf[j];
+#pragma unroll
+    for (int j = 0; j < E::O; ++j) {
+        d.obs[j * ld + i] = obf[j];
+#pragma unroll
+        for (int k = 0; k < NI; ++k) d.jac_o[((size_t)j * NI + k) * ld + i] = ob[j].d[k];
+    }
+#pragma unroll
+    for (int k = 0; k < NI; ++k) d.jac_r[(size_t)k * ld + i] = o.rew.d[k];
+    d.step[i] = step;
+    if (E::FINAL != FINAL_NONE) d.yielded[i] = yielded;
 }
 
 // ---------------------------------------------------------------------------------------------------- rollout kernel
@@ -1436,7 +1466,7 @@ enum RolloutVariant { RV_PLAIN = 0, RV_WS256 = 1, RV_WS64 = 2 };
 // per-family launchers: defined (explicitly instantiated) in vecsim_family.hip, one translation unit per family
 template <class E>
 struct Launch {
-    static void step(vs_env* h, const float* act, long es, long ds);
+    static void step(vs_env* h, const float* act, long es, long ds, int rec = 0, int row = 0);
     static void rollout(vs_env* h, int k, uint64_t seed, uint64_t ep, int rec);
     static int variant(vs_env* h);  // RolloutVariant vs_step_random would launch for the handle's configuration
     static void jac(vs_env* h, const float* act, long es, long ds);
@@ -1483,16 +1513,23 @@ int Launch<E>::variant(vs_env* h) {
     return RV_PLAIN;
 }
 
-template <class E>
-void Launch<E>::step(vs_env* h, const float* act, long es, long ds) {
+template <class E, int REC>
+static void launch_step_rec(vs_env* h, const float* act, long es, long ds, int row) {
     dim3 g = grid_for(h->d.ld), b(BLOCK);
     bool uni = h->uniform && h->dr.n == 0 && h->d.pbuf_n == 0;
-#define LS(U, AR, PI) hipLaunchKernelGGL((k_step<E, U, AR, PI>), g, b, 0, h->stream, h->task, h->d, act, es, ds, h->ar_seed)
+#define LS(U, AR, PI) hipLaunchKernelGGL((k_step<E, U, AR, PI, REC>), g, b, 0, h->stream, h->task, h->d, act, es, ds, h->ar_seed, row)
     if (h->d.pipe.act_on || h->d.pipe.obs_on) {  // the wrapper pipeline: per-env-constant variant only
         if (h->auto_reset) LS(false, true, true); else LS(false, false, true);
     } else if (h->auto_reset) { if (uni) LS(true, true, false); else LS(false, true, false); }
     else { if (uni) LS(true, false, false); else LS(false, false, false); }
 #undef LS
+}
+
+template <class E>
+void Launch<E>::step(vs_env* h, const float* act, long es, long ds, int rec, int row) {
+    if (rec == 0) launch_step_rec<E, 0>(h, act, es, ds, 0);
+    else if (rec == 1) launch_step_rec<E, 1>(h, act, es, ds, row);
+    else launch_step_rec<E, 2>(h, act, es, ds, row);
 }
 
 template <class E, bool U, bool AR, int NE>

@@ -379,56 +379,38 @@ class ParallelRolloutSampler:
             def final_state(length, T):  # ... and VS_STATE / VS_HIDDEN the state it belongs to
                 return st_t.t(), (hid_t.t() if H else None)
         else:
+            # policy in the loop: rollout() with the caller's policy (rollout.py:185-258).  One recording step kernel per env
+            # step -- vs_step_record writes the observation the policy saw, its action, the reward, the done bit and (full
+            # records) state / applied action / hidden state into the same device-side planes the fused path fills -- so a
+            # step costs the policy's own kernels plus two launches (observation transpose, step) and nothing is cloned.
             policy = self.policy.to(dev) if hasattr(self.policy, "to") else self.policy
             if hasattr(policy, "eval"):
                 policy.eval() if eval else policy.train()
-            obs_rec, act_rec, rew_rec, done_rec, st_rec, hid_rec = [], [], [], [], [], []
-            alive = torch.ones(n, dtype=torch.bool, device=dev)
+            if hasattr(policy, "reset"):
+                policy.reset()
+            v.set_record_mode(2 if full else 1)
+            v.set_traj_capacity(T_cap)
+            v.set_traj_offset(0)
             # rollout() stops stepping an env at done (rollout.py:185): finished lanes are frozen by the step kernel, so
             # nothing the policy makes of their last observation can move them or raise their NaN flag
             v.set_freeze_done(True)
-            # env.limit_act of the outermost env: the projection onto the act space the policy sees
-            from .spaces import BoxSpace
-
-            box_act = isinstance(self.env.act_space, BoxSpace)
-            if box_act:
-                a_lo, a_hi = (torch.as_tensor(np.asarray(b, dtype=np.float32), device=dev) for b in self.env.act_space.bounds)
             with torch.no_grad():
                 while t < T_cap:
-                    obs_now = visible(obs_full, 0).t().contiguous()  # [n, O']: what the policy sees and what is recorded
+                    obs_now = visible(obs_full, 0).t().contiguous()  # [n, O']: what the policy sees
                     act = policy(obs_now).to(torch.float32).reshape(n, A).contiguous()
-                    obs_rec.append(obs_now)
-                    act_rec.append(act)
-                    if full:
-                        st_rec.append(st_t.t().clone())
-                        if H:
-                            hid_rec.append(hid_t.t().clone())
-                    v.step(act)
-                    rew_rec.append(rew_t.clone())
-                    done_rec.append(done_t.clone())
+                    v.step_record(act, row=t)
                     t += 1
-                    if t % 32 == 0 or t == T_cap:
-                        alive &= ~torch.stack(done_rec[-32:]).bool().any(dim=0)
-                        if not bool(alive.any()):
-                            break
+                    if (t % 32 == 0 or t == T_cap) and bool(done_t.bool().all()):  # one scalar sync per 32 steps
+                        break
             v.set_freeze_done(False)
-            obs_T, act_T = torch.stack(obs_rec), torch.stack(act_rec)  # [T, n, dim]
-            rew_T, done_T = torch.stack(rew_rec), torch.stack(done_rec).bool()
-            if full:
-                st_T = torch.stack(st_rec)
-                hid_T = torch.stack(hid_rec) if H else None
+            fields = v.record_fields()
+            done_T = v.traj_done(t, n)  # [T, n]
 
             def gather(ti, li):
-                extra = None
-                if full:
-                    a_ = act_T[ti, li]
-                    if box_act:
-                        app_ = torch.minimum(torch.maximum(a_, a_lo), a_hi)
-                    else:  # a discrete act space snaps to its closest element: per row on the host, exact and rare
-                        proj = np.stack([self.env.act_space.project_to(r) for r in a_.cpu().numpy().astype(np.float64)])
-                        app_ = torch.as_tensor(proj.astype(np.float32), device=dev).reshape(a_.shape)
-                    extra = (st_T[ti, li], app_, hid_T[ti, li] if H else a_[:, :0])
-                return obs_T[ti, li], act_T[ti, li], rew_T[ti, li], extra
+                rec = v.gather_traj(ti, li)
+                col = lambda k: rec[:, fields[k][0]:fields[k][0] + fields[k][1]]
+                extra = (col("state"), col("act_app"), col("hidden")) if full else None
+                return visible(col("obs"), 1), col("act"), rec[:, fields["rew"][0]], extra
 
             def final_obs(length, T):  # finished lanes are frozen: VS_OBS is the observation after every lane's last step
                 return visible(obs_full, 0).t()

@@ -336,6 +336,17 @@ class VecSimEnv:
         es, ds = self._act_strides(actions)
         self._check(self._lib.vs_step(self._h, C.c_void_p(actions.data_ptr()), es, ds), "vs_step")
 
+    def step_record(self, actions, row=None):
+        """step() that also writes the step's record (the observation the policy saw, its action, reward, done bit; in
+        record mode 2 also state / applied action / hidden state) into row `row` of the trajectory buffers; row=None uses
+        and advances the handle's device-side row counter (set_record_row), which is what a captured graph needs"""
+        es, ds = self._act_strides(actions)
+        self._check(self._lib.vs_step_record(self._h, C.c_void_p(actions.data_ptr()), es, ds, -1 if row is None else int(row)),
+                    "vs_step_record")
+
+    def set_record_row(self, row=0):
+        self._check(self._lib.vs_set_record_row(self._h, int(row)), "vs_set_record_row")
+
     def seek_random(self, step_index=0):
         """Reposition the action stream of step_random (absolute step index, see include/vecsim.h)."""
         self._check(self._lib.vs_seek_random(self._h, int(step_index)), "vs_seek_random")
