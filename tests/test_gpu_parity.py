@@ -1238,3 +1238,37 @@ def test_nan_flag_is_the_same_in_every_fused_kernel(vs, auto_reset):
     expect[[5, 64, 699]] = 1
     for variant, f in flags.items():
         assert np.array_equal(f, expect), variant
+
+
+@pytest.mark.parametrize("name", ["bob", "omo", "qbb"])
+def test_long_launches_with_many_resets_equal_the_plain_kernel(vs, name):
+    """one launch of 300 recorded steps with auto-reset for the families with short episodes (ball-on-beam: 73 steps on
+    average): every lane resets several times inside the launch, through the reset stock of k_rollout_ws (refilled every 32
+    steps) and, where a lane resets twice between refills, through its own draw -- records, final buffers and episode
+    statistics must equal k_rollout's bit for bit in both workgroup shapes"""
+    L = vs._lib
+    n, T = 2048, 300
+    out = {}
+    for variant in ("k_rollout", "k_rollout_ws", "k_rollout_ws64"):
+        e = vs.VecSimEnv(name, n, **dict(KW[name], max_steps=90))
+        e.set_params(np.tile(vs.nominal_params(name), (n, 1)))
+        e.set_rollout_variant(variant)
+        e.set_auto_reset(True, seed=11)
+        e.reset(seed=12)
+        e.set_record_mode(2)
+        e.set_traj_capacity(T)
+        e.step_random(T, seed=13, record=True)
+        tt = e.traj_tensors(T)
+        out[variant] = (tt["rec"].clone(), tt["done"].clone(), {w: e.get(w) for w in (L.VS_STATE, L.VS_HIDDEN, L.VS_STEPCOUNT,
+                        L.VS_RETURNS, L.VS_EPSTAT_COUNT, L.VS_EPSTAT_RETSUM, L.VS_EPSTAT_LENSUM)})
+        assert e.error_count() == 0
+        e.close()
+    rec_a, done_a, fin_a = out["k_rollout"]
+    assert int(done_a.sum()) >= 3 * n  # every lane finished (and restarted) several episodes
+    gaps = torch.diff(torch.nonzero(done_a[:, 0]).flatten())
+    for variant in ("k_rollout_ws", "k_rollout_ws64"):
+        rec_b, done_b, fin_b = out[variant]
+        assert torch.equal(rec_a, rec_b) and torch.equal(done_a, done_b), variant
+        for w in fin_a:
+            assert np.array_equal(fin_a[w], fin_b[w]), (variant, w)
+    assert len(gaps) >= 2
