@@ -325,6 +325,10 @@ def measure(args, rank, world, local_rank, dist, rehearsal):
         torch.cuda.synchronize()
         return time.perf_counter() - t0
 
+    # pre-roll (untimed, before the W warm-up launches): the GPU comes out of the host-side set-up idle and its clock takes
+    # some 10 ms of work to ramp -- a 20-launch timed region (1 ms) right behind a 5-launch warm-up would measure the ramp
+    if args.mode == "fused":
+        run(int(os.environ.get("BENCH_PREROLL", "400")))
     run(max(args.warmup, 1))
     el = timed(steps)  # THE timed region: exactly `steps` launches between two barriers + synchronisations
     repeats = [timed(steps) for _ in range(3)]  # untimed by the contract: run-to-run spread of the same region
