@@ -750,7 +750,7 @@ struct Qbb : EnvDefaults<2> {
         R sx, cx, sy, cy, sa, ca, sb, cb;
         sincos_fast(th_x, &sx, &cx);
         sincos_fast(h[0], &sa, &ca);
-#ifdef VS_QBB_HALF  // diagnostic builds only: what ONE axis of the ball balancer costs (results are wrong)
+#ifdef VS_QBB_HALF  // diagnostic builds only: what ONE axis of the ball balancer costs (results are wrong; DESIGN.md section 4)
         sy = sx, cy = cx, sb = sa, cb = ca;
         th_y_dot = th_x_dot, y = x, y_dot = x_dot, a1 = a0;
 #else
