@@ -218,6 +218,13 @@ struct EnvDefaults {
     static constexpr int WS_SHAPE_FULL = 64;
     // ... and whether 64-env workgroups still pay between 256 and 384 envs per compute unit (needs <= 168 VGPRs)
     static constexpr bool WS_MID = true;
+    // ... and up to how many envs per compute unit the 64-env workgroups are used whatever WS_SHAPE_FULL says
+    static constexpr int WS_SMALL = 64;
+    // ... and whether its reward wave, which draws the policy's actions, also pre-processes them for the physics wave, for a
+    // family whose physics wave is by far the longer one: 1 = ActNorm -> clip (needs action bounds that are plain numbers:
+    // the reward wave's constants may be stale under live randomisation), 2 = ActNorm -> clip -> dead zone (the family
+    // then provides dead_zone() and dynamics_core(), and never runs this kernel under live randomisation)
+    static constexpr int WS_PREP_C = 0;
     // ... and which of its two waves draws the policy's actions when steps are recorded: the physics wave where the other one
     // is the longer (it finishes observe() and stores the records), see k_rollout_ws
     static constexpr bool WS_DRAW_P = false;
@@ -488,6 +495,7 @@ struct QcpT : EnvDefaults<1> {
     static constexpr bool REWARD_SIDE_USES_CONSTS = false;
     static constexpr int WS_SHAPE_FULL = 256;
     static constexpr bool WS_MID = false;
+    static constexpr int WS_PREP_C = 1;  // a chain of four dependent _dynamics evaluations: every instruction off it counts
     static constexpr bool SYMMETRIC_BOX = V == 0;
     static constexpr int FINAL = V == 1 ? FINAL_STATE_TIME : FINAL_NONE;
     enum { C_KA, C_ETA_M, C_KB, C_MTG, C_MPL2, C_MU, C_M00, C_MPL, C_M11, C_BEQ, C_BP, C_MPLG, C_TH_NEG, C_TH_POS,
@@ -694,9 +702,11 @@ __device__ inline float qbb_ik(float th, float r, float l) {
 struct Qbb : EnvDefaults<2> {
     static constexpr int S = 8, A = 2, O = 8, H = 2, I = 4, P = 20, K = 19, KS = 17;
     static constexpr int REW = REW_SCALED_EXP, RADIAL = -1;
-    // 17-float messages, a physics side 3x the reward side and 350 VGPRs: the split pays only while each of its two waves has
-    // a SIMD of its own (up to 128 envs per compute unit: +10 %), see Launch<E>::variant
-    static constexpr bool WS_PAYS = false;
+    // A physics wave more than twice the reward wave and ~400 VGPRs: 64-env workgroups while each of the two waves has a SIMD
+    // of its own (up to 128 envs per compute unit), 256-env ones (capped at 256 VGPRs) up to 256; with the reward wave
+    // pre-processing the actions (WS_PREP_C) 62 against k_rollout's 100 us per 100 steps at 32 768 envs, 83 against 107 at 65 536
+    static constexpr int WS_SHAPE_FULL = 256, WS_SMALL = 128;
+    static constexpr bool WS_MID = false;
     enum { C_AM, C_BEQV, C_JEQ, C_CKIN, C_OFFX, C_OFFY, C_TXP, C_TXN, C_TYP, C_TYN, C_BDR2, C_JBR, C_MR2, C_CKMGR2,
            C_ZETA, C_XMAX, C_CMAX, C_IK_X0, C_IK_Y0 };
     static constexpr int CMAX = C_CMAX;
@@ -737,12 +747,24 @@ struct Qbb : EnvDefaults<2> {
     __device__ static void act_bounds(const float*, float* lo, float* hi) {
         hi[0] = hi[1] = 3.0f; lo[0] = lo[1] = -3.0f;  // MAX_ACT_QBB
     }
+    static constexpr int WS_PREP_C = 2;
     template <class R>
-    __device__ static void dynamics(const Task& T, const float* c, R* s, R* h, const R* act, const R*) {  // :247-330
+    __device__ static void dead_zone(const Task& T, const float* c, R* a) {  // :261-264
         bool simple = (T.flags & 1) != 0;
-        R a0 = act[0], a1 = act[1];
-        if (!simple && c[C_TXN] <= a0 && a0 <= c[C_TXP]) a0 = 0.f;  // dead zones :261-264
-        if (!simple && c[C_TYN] <= a1 && a1 <= c[C_TYP]) a1 = 0.f;
+        if (!simple && c[C_TXN] <= a[0] && a[0] <= c[C_TXP]) a[0] = 0.f;
+        if (!simple && c[C_TYN] <= a[1] && a[1] <= c[C_TYP]) a[1] = 0.f;
+    }
+    template <class R>
+    __device__ static void dynamics(const Task& T, const float* c, R* s, R* h, const R* act, const R* tr) {  // :247-330
+        R u[2] = {act[0], act[1]};
+        dead_zone(T, c, u);
+        dynamics_core(T, c, s, h, u, tr);
+    }
+    // the step behind the dead zones (u: the voltages that reach the servos)
+    template <class R>
+    __device__ static void dynamics_core(const Task& T, const float* c, R* s, R* h, const R* u, const R*) {
+        bool simple = (T.flags & 1) != 0;
+        R a0 = u[0], a1 = u[1];
         R th_x = s[0] + c[C_OFFX], th_y = s[1] + c[C_OFFY];
         R x = s[2], y = s[3], th_x_dot = s[4], th_y_dot = s[5], x_dot = s[6], y_dot = s[7];
         R th_x_ddot = (c[C_AM] * a0 - c[C_BEQV] * th_x_dot) * c[C_JEQ];  // C_JEQ holds 1 / J_eq

@@ -880,7 +880,13 @@ __global__ __launch_bounds__(2 * NE) void k_rollout_ws(Task T, Dev d, int k_step
     constexpr int TR0 = E::S, HM0 = E::S + (REC ? E::TRIG : 0), AM0 = HM0 + HM;  // offsets inside the message
     constexpr int NT = E::TRIG > 0 ? E::TRIG : 1, NH = E::H > 0 ? E::H : 1;
     __shared__ __attribute__((aligned(16))) float l_msg[2][WS_R][M * NE];
-    __shared__ __attribute__((aligned(16))) float l_act[DP ? 1 : 2][DP ? 1 : WS_R][DP ? 4 : E::A * NE];
+    // PC ("prep on C"): the C wave, which draws the actions, also runs ActNorm -> clip -> dead zone on them and hands the P
+    // wave the voltages that reach the dynamics, next to the raw action it keeps for its own reward / record
+    constexpr int PCL = DP ? 0 : E::WS_PREP_C;  // 0: no, 1: ActNorm -> clip, 2: + dead zone (see EnvDefaults::WS_PREP_C)
+    constexpr bool PC = PCL > 0;
+    static_assert(PCL != 2 || E::REWARD_SIDE_USES_CONSTS, "a dead zone on the C wave reads per-env constants");
+    constexpr int AW = PC ? 2 * E::A : E::A;  // floats per step in l_act: [u | a] or [a]
+    __shared__ __attribute__((aligned(16))) float l_act[DP ? 1 : 2][DP ? 1 : WS_R][DP ? 4 : AW * NE];
     // The reset stock (auto-reset only): the C wave keeps, per lane, the init-space sample of the lane's NEXT episode (and
     // the trig of that state) ready in LDS, tagged with the episode counter it was drawn for.  A resetting lane of the P
     // wave takes it with a handful of LDS reads instead of running Philox + sample_init + observe_p for the one or two
@@ -917,7 +923,7 @@ __global__ __launch_bounds__(2 * NE) void k_rollout_ws(Task T, Dev d, int k_step
     const uint64_t blk0 = epoch0 / SPB;
     uint4 carry = make_uint4(0, 0, 0, 0);
     // the actions of batch bb: act_space.sample_uniform() per step (all WS_R of them: a ragged last batch ignores the rest)
-    auto draw_batch = [&](int bb, float (*a_out)[E::A]) __attribute__((always_inline)) {
+    auto draw_batch = [&](int bb, float (*a_out)[AW]) __attribute__((always_inline)) {
         uint32_t w[(NBLK + 1) * 4];
         w[0] = carry.x, w[1] = carry.y, w[2] = carry.z, w[3] = carry.w;
 #pragma unroll
@@ -934,7 +940,24 @@ __global__ __launch_bounds__(2 * NE) void k_rollout_ws(Task T, Dev d, int k_step
 #pragma unroll
                 for (unsigned p2 = 1; p2 < SPB; ++p2) bits = ph == p2 ? w[(r + p2) * E::A + j] : bits;
                 bool nrm = (T.flags & VS_FLAG_ACT_NORM) != 0;
-                a_out[r][j] = E::sample_action(c, nrm ? -1.0f : alo[j], nrm ? 1.0f : ahi[j], Rng::to_u01(bits), j);
+                a_out[r][(PC ? E::A : 0) + j] = E::sample_action(c, nrm ? -1.0f : alo[j], nrm ? 1.0f : ahi[j], Rng::to_u01(bits), j);
+            }
+            if constexpr (PC) {
+                // ActNorm -> limit_act -> dead zone, statement for statement what the P wave (and step_one) would do
+                const float* a = a_out[r] + E::A;
+                float an[E::A], ac[E::A];
+                const bool nrm = (T.flags & VS_FLAG_ACT_NORM) != 0;
+                float lb[E::A], ub[E::A];
+                E::act_bounds(c, lb, ub);
+#pragma unroll
+                for (int j = 0; j < E::A; ++j) {
+                    float m = lb[j] + (a[j] + 1.0f) * (ub[j] - lb[j]) * 0.5f;
+                    an[j] = vsel(nrm, m, a[j]);
+                }
+                E::limit_act(c, alo, ahi, an, ac);
+                if constexpr (PCL == 2) E::dead_zone(T, c, ac);
+#pragma unroll
+                for (int j = 0; j < E::A; ++j) a_out[r][j] = ac[j];
             }
         }
     };
@@ -960,12 +983,12 @@ __global__ __launch_bounds__(2 * NE) void k_rollout_ws(Task T, Dev d, int k_step
         auto p_batch = [&](auto full_tag, int b, int nr) __attribute__((always_inline)) {
             constexpr bool FULL = decltype(full_tag)::value;
             // all actions of the batch up front: one LDS round trip per batch instead of one per step on the critical path
-            float a_all[WS_R][E::A];
+            float a_all[WS_R][AW];
             if (DP) {
                 draw_batch(b, a_all);
             } else {
 #pragma unroll
-                for (int r = 0; r < WS_R; ++r) Planes<E::A>::load(l_act[b & 1][r], NE, le, a_all[r]);
+                for (int r = 0; r < WS_R; ++r) Planes<AW>::load(l_act[b & 1][r], NE, le, a_all[r]);
             }
 #pragma unroll
             for (int r = 0; r < WS_R; ++r) {
@@ -985,19 +1008,25 @@ __global__ __launch_bounds__(2 * NE) void k_rollout_ws(Task T, Dev d, int k_step
                 bool fin = false;  // (used for the reset on this side)
                 if (!frozen) {
                     // the P half of step_one: ActNorm -> limit_act -> _step_dynamics -> curr_step += 1 -> is_done
-                    float an[E::A], ac[E::A];
-                    {
-                        const bool nrm = (T.flags & VS_FLAG_ACT_NORM) != 0;
-                        float lb[E::A], ub[E::A];
-                        E::act_bounds(c, lb, ub);
+                    if constexpr (PCL == 2) {
+                        E::dynamics_core(T, c, s, h, a, (REC && E::TRIG > 0) ? (const float*)tr : (const float*)nullptr);
+                    } else if constexpr (PCL == 1) {
+                        E::dynamics(T, c, s, h, a, (REC && E::TRIG > 0) ? (const float*)tr : (const float*)nullptr);
+                    } else {
+                        float an[E::A], ac[E::A];
+                        {
+                            const bool nrm = (T.flags & VS_FLAG_ACT_NORM) != 0;
+                            float lb[E::A], ub[E::A];
+                            E::act_bounds(c, lb, ub);
 #pragma unroll
-                        for (int j = 0; j < E::A; ++j) {
-                            float m = lb[j] + (a[j] + 1.0f) * (ub[j] - lb[j]) * 0.5f;
-                            an[j] = vsel(nrm, m, a[j]);
+                            for (int j = 0; j < E::A; ++j) {
+                                float m = lb[j] + (a[j] + 1.0f) * (ub[j] - lb[j]) * 0.5f;
+                                an[j] = vsel(nrm, m, a[j]);
+                            }
                         }
+                        E::limit_act(c, alo, ahi, an, ac);
+                        E::dynamics(T, c, s, h, ac, (REC && E::TRIG > 0) ? (const float*)tr : (const float*)nullptr);
                     }
-                    E::limit_act(c, alo, ahi, an, ac);
-                    E::dynamics(T, c, s, h, ac, (REC && E::TRIG > 0) ? (const float*)tr : (const float*)nullptr);
                     // the trig of the new state right behind the dynamics, in the same basic block as the bounds test and the
                     // message below: independent work for the scheduler to interleave (a lane that resets redoes it)
                     if (REC) E::observe_p(s, tr);
@@ -1136,10 +1165,10 @@ __global__ __launch_bounds__(2 * NE) void k_rollout_ws(Task T, Dev d, int k_step
         if (!DP) carry = Rng::philox(seed, d.idx0 + (uint32_t)i, RNG_ACT, blk0);
         auto draw = [&](int bb) __attribute__((always_inline)) {
             if (DP) return;
-            float a_new[WS_R][E::A];
+            float a_new[WS_R][AW];
             draw_batch(bb, a_new);
 #pragma unroll
-            for (int r = 0; r < WS_R; ++r) Planes<E::A>::store(l_act[DP ? 0 : (bb & 1)][DP ? 0 : r], NE, le, a_new[r]);
+            for (int r = 0; r < WS_R; ++r) Planes<AW>::store(l_act[DP ? 0 : (bb & 1)][DP ? 0 : r], NE, le, a_new[r]);
         };
         // Reward, returns and records of the steps of batch bb, in three passes so that the arithmetic of the WS_R steps --
         // independent of each other -- sits in ONE basic block (instruction-level parallelism for a wave that otherwise
@@ -1154,6 +1183,11 @@ __global__ __launch_bounds__(2 * NE) void k_rollout_ws(Task T, Dev d, int k_step
                 if (DP) {
 #pragma unroll
                     for (int j = 0; j < E::A; ++j) a[r][j] = v[r][AM0 + j];
+                } else if (PC) {
+                    float ua[AW];
+                    Planes<AW>::load(l_act[DP ? 0 : (bb & 1)][DP ? 0 : r], NE, le, ua);
+#pragma unroll
+                    for (int j = 0; j < E::A; ++j) a[r][j] = ua[E::A + j];
                 } else {
                     Planes<E::A>::load(l_act[DP ? 0 : (bb & 1)][DP ? 0 : r], NE, le, a[r]);
                 }
@@ -1485,8 +1519,8 @@ void launch_step_mixed(const Segs* dev_segs, int total_blocks, hipStream_t st, b
 //   * the wave-specialised kernel pays while k_rollout would leave a SIMD with a single wave, for the families whose step
 //     splits into two comparable halves, and needs constants its reward wave reads not to change inside the launch;
 //   * up to 64 envs per compute unit (16 384): 64-env workgroups -- every family (4 096 QQube envs: 43.7 against 47.9 us);
-//     the ball balancer up to 128 per CU (its two waves then have a SIMD each: +10 %; beyond that its 350 VGPRs allow no
-//     second wave per SIMD and k_rollout wins);
+//     the ball balancer up to 128 per CU (E::WS_SMALL: its two waves then have a SIMD each; its ~400 VGPRs allow no second
+//     wave of that shape per SIMD);
 //   * up to 256 envs per compute unit (65 536): 256-env workgroups (one per CU, a P and a C wave on every SIMD) or
 //     64-env ones, whichever the family runs faster (E::WS_SHAPE_FULL); with a live randomizer the 64-env shape: a
 //     resetting lane's redraw stalls one pair of waves instead of four (QQube, 7 parameters: 120 against 169 us);
@@ -1506,8 +1540,8 @@ int Launch<E>::variant(vs_env* h) {
     if (force && force[0] == 'p') return RV_PLAIN;
     if (force && force[0] == 'w') return force[1] && force[2] == '6' ? RV_WS64 : RV_WS256;
     const int64_t ld = h->d.ld, cu = h->n_cu;
-    if (ld <= 64 * cu) return RV_WS64;
-    if (!E::WS_PAYS) return ld <= 128 * cu ? RV_WS64 : RV_PLAIN;
+    if (ld <= E::WS_SMALL * cu) return RV_WS64;
+    if (!E::WS_PAYS) return RV_PLAIN;
     if (ld <= 256 * cu) return live ? RV_WS64 : (E::WS_SHAPE_FULL == 64 ? RV_WS64 : RV_WS256);
     if (ld <= 384 * cu && E::WS_MID) return RV_WS64;
     return RV_PLAIN;

@@ -1066,7 +1066,7 @@ def test_rollout_variant_selection(vs):
         assert big.rollout_variant() == expect, n_big
         big.close()
     for name, n, expect in (("omo", 4096, "k_rollout_ws64"), ("qbb", 4096, "k_rollout_ws64"), ("qbb", 32768, "k_rollout_ws64"),
-                            ("qbb", 65536, "k_rollout"), ("qcp-st", 4096, "k_rollout"), ("bob", 65536, "k_rollout_ws"),
+                            ("qbb", 65536, "k_rollout_ws"), ("qbb", 98304, "k_rollout"), ("qcp-st", 4096, "k_rollout"), ("bob", 65536, "k_rollout_ws"),
                             ("bob-d", 65536, "k_rollout_ws64"), ("bob", 98304, "k_rollout_ws64"), ("qcp-su", 65536, "k_rollout_ws"),
                             ("qcp-su", 98304, "k_rollout"), ("qq-su", 4096, "k_rollout_ws64"), ("qq-su", 32768, "k_rollout_ws64"),
                             ("omo", 65536, "k_rollout_ws64")):
