@@ -11,7 +11,7 @@ parallel_rollout_sampler.py:216-230).  The parent never touches the GPU.  Under 
 RANK / WORLD_SIZE (the driver's torchrun line) the process is a rank itself.
 
 A "step" is one pass of the hot path over the batch = one launch.  In the default fused mode a launch advances every one of
-the 65 536 environments of a rank by `--chunk` (100) env steps -- SimPyEnv.step: reward -> clip -> dead zone -> integrate
+the 65 536 environments of a rank by `--chunk` (400) env steps -- SimPyEnv.step: reward -> clip -> dead zone -> integrate
 -> done -> observe, finished lanes auto-reset in the same kernel, actions from the on-device uniform random policy
 (DummyPolicy), obs/act/rew/done of every env step recorded; in `--mode step` a launch is one env step.  `value` counts ENV
 steps: envs x env-steps-per-launch x K / time ("env_steps_per_step" in the JSON).  State and constants are resident in HBM
@@ -58,6 +58,7 @@ ACT_HI = {"omo": 30.0, "bob": 29.43, "qq-su": 4.5, "qcp-su": 6.0, "qbb": 3.0, "q
           "bob-d": 29.43}
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_ACHIEVABLE_GBS = 6290.0  # what a float4 copy reaches there (79 % of spec)
+DEFAULT_CHUNK = 400  # env steps per launch: the fixed cost of a launch (dispatch, pipeline fill and drain: ~6 us) is 3 % of it
 RECORD_BUFFER_BYTES = 1.25 * 2 ** 30  # rotating record buffer: > 1 GiB, several times the 256 MiB Infinity Cache
 
 
@@ -224,7 +225,7 @@ def parse_args():
     ap.add_argument("--envs", type=int, default=65536, help="envs per GPU")
     ap.add_argument("--env", default="qq-su", choices=sorted(DIMS))
     ap.add_argument("--mode", default="fused", choices=["fused", "step"])
-    ap.add_argument("--chunk", type=int, default=100, help="env steps per launch in fused mode")
+    ap.add_argument("--chunk", type=int, default=DEFAULT_CHUNK, help="env steps per launch in fused mode")
     ap.add_argument("--record", type=int, default=1, help="0 none, 1 obs|act|rew, 2 + state|act_app|hidden")
     ap.add_argument("--per-env-params", type=int, default=1, help="1: per-env constants [K][N] (DR-capable), 0: broadcast")
     ap.add_argument("--live-dr", type=int, default=0, help="DomainRandWrapperLive on the device: redraw the first K parameters "
@@ -489,8 +490,8 @@ def roofline(args, env, local_rank, d, n, chunk, ms_region=None):
         tf = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))[-1]
         tab = json.load(open(tf))
         key = None
-        if (args.mode == "fused" and args.env == "qq-su" and n == 65536 and chunk == 100 and args.record == 1
-                and args.per_env_params == 1):
+        if (args.mode == "fused" and args.env == "qq-su" and n == 65536 and args.record == 1 and args.per_env_params == 1
+                and chunk == tab.get("fused_default", {}).get("chunk")):
             key = "fused_default"
         elif args.mode == "step" and args.env == "qq-su" and n == 16777216:
             key = "step_16m"

@@ -43,6 +43,7 @@ res = {"lib_version": int(L.load().vs_version()),
        "fused_default": block("fetch", "write", bd["roofline"]["kernel"], bd["roofline"]["alg_bytes_per_launch"],
                               "bench.py --no-cpu-baseline --no-extras --steps 300 --warmup 50")}
 bs = last_json(f"{prof}/bench_step16m.json")
+res["fused_default"]["chunk"] = bd["config"]["chunk"]  # env steps per launch of the profiled command
 res["step_16m"] = block("fetch_step16m", "write_step16m", "k_step", bs["roofline"]["alg_bytes_per_launch"],
                         "bench.py --no-cpu-baseline --no-extras --mode step --envs 16777216 --steps 30 --warmup 5")
 json.dump(res, open(out, "w"), indent=1)

@@ -1266,7 +1266,6 @@ __global__ __launch_bounds__(2 * NE) void k_rollout_ws(Task T, Dev d, int k_step
         };
         __builtin_amdgcn_s_waitcnt(0x0F70);
         draw(0);
-        refill();  // every lane's first entry: one full-wave pass per launch
         ws_barrier();
 #ifdef VS_WS_NOC  // diagnostic: the C wave only keeps the barriers
         for (int b = 0; b < nb; ++b) ws_barrier();
@@ -1280,7 +1279,9 @@ __global__ __launch_bounds__(2 * NE) void k_rollout_ws(Task T, Dev d, int k_step
             if (b >= 1) work(b - 1);  // reads l_act[(b - 1) & 1] before draw(b + 1) overwrites the same buffer
             VS_STAMP(st1);
             if (b + 1 < nb) draw(b + 1);
-            if ((b & (WS_REFILL - 1)) == WS_REFILL - 1) refill();
+            // (b == 0 fills every lane's first entry while this wave has no batch to work off yet: a lane of P that resets
+            // before its entry is there draws for itself)
+            if ((b & (WS_REFILL - 1)) == 0) refill();
             VS_STAMP(st2);
             ws_barrier();
 #ifdef VS_WS_STAMP

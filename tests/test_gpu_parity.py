@@ -978,11 +978,13 @@ def test_step_jacobians_against_the_forks_autograd(vs, golden_dir):
 
 def test_headline_launch_values_at_65536(vs):
     """The exact launch bench.py times -- 65 536 QQubeSwingUpSim envs, per-env constants, auto-reset, every step recorded,
-    100 steps per launch, k_rollout_ws in 64-env workgroups (four per compute unit) -- checked for VALUES: records, final
-    buffers and episode statistics equal the plain kernel's bit for bit (and the 256-env shape's), 512 lanes of the last
+    bench.py's default steps per launch, k_rollout_ws in 64-env workgroups (four per compute unit) -- checked for VALUES:
+    records, final buffers and episode statistics equal the plain kernel's bit for bit (and the 256-env shape's), 512 lanes of the last
     recorded step are re-stepped by the fp64 oracle, and the record planes hold what rollout() keeps (mode 2)."""
     L = vs._lib
-    n, T = 65536, 100
+    import bench
+
+    n, T = 65536, bench.DEFAULT_CHUNK
     trio = {}
     for variant in ("k_rollout", "k_rollout_ws", "k_rollout_ws64"):
         e = vs.VecSimEnv("qq-su", n, **KW["qq-su"])
@@ -993,9 +995,9 @@ def test_headline_launch_values_at_65536(vs):
         e.reset(seed=2)
         e.set_record_mode(2)
         e.set_traj_capacity(2 * T)
-        e.step_random(T, seed=3, record=True)  # rows 0 .. 99
+        e.step_random(T, seed=3, record=True)  # rows 0 .. T-1
         e.set_traj_offset(T)
-        e.step_random(T, seed=3, record=True)  # rows 100 .. 199: a second launch continues the streams
+        e.step_random(T, seed=3, record=True)  # rows T .. 2T-1: a second launch continues the streams
         trio[variant] = e
     auto = vs.VecSimEnv("qq-su", n, **KW["qq-su"])
     assert auto.rollout_variant() == "k_rollout_ws64"  # what the automatic choice (and bench.py) launches at this size
