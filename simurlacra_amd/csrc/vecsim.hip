@@ -381,7 +381,7 @@ int vs_create(int env_type, int64_t n_envs, double dt, int64_t max_steps, int de
     CK(dalloc(h, &h->d_counter, (size_t)1));
     CK(dalloc(h, &d.rec_row, (size_t)1));
 #ifdef VS_WS_STAMP
-    CK(dalloc(h, &d.dbg, (size_t)(ld / 64) * 8));
+    CK(dalloc(h, &d.dbg, (size_t)(ld / 64) * 12));
 #endif
 
     float nominal[MAXP];
@@ -742,7 +742,7 @@ int vs_set_freeze_done(vs_handle h, int on) {
 }
 
 int vs_set_rollout_variant(vs_handle h, int variant) {
-    if (!h || variant < -1 || variant > 2) return fail(h, VS_ERR_ARG, "vs_set_rollout_variant: -1 (automatic), 0, 1 or 2");
+    if (!h || variant < -1 || variant > 4) return fail(h, VS_ERR_ARG, "vs_set_rollout_variant: -1 (automatic) or 0 .. 4");
     h->rollout_variant = variant;
     return VS_OK;
 }
@@ -896,7 +896,7 @@ static bool buf_info(vs_handle h, int which, void** p, size_t* bytes) {
         case VS_JAC_REW: *p = d.jac_r; *bytes = d.jac_r ? (size_t)(ei.S + ei.A) * ld * 4 : 0; return true;
         case VS_JAC_OBS: *p = d.jac_o; *bytes = d.jac_o ? (size_t)ei.O * (ei.S + ei.A) * ld * 4 : 0; return true;
 #ifdef VS_WS_STAMP
-        case 99: *p = d.dbg; *bytes = (size_t)(ld / 64) * 8 * 8; return true;
+        case 99: *p = d.dbg; *bytes = (size_t)(ld / 64) * 12 * 8; return true;
 #endif
 
         default: return false;

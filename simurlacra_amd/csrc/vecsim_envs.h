@@ -228,6 +228,12 @@ struct EnvDefaults {
     // ... and which of its two waves draws the policy's actions when steps are recorded: the physics wave where the other one
     // is the longer (it finishes observe() and stores the records), see k_rollout_ws
     static constexpr bool WS_DRAW_P = false;
+    // ... and whether a THIRD wave per 64 envs pays (k_rollout_ws with NR = 3: a generator wave draws the actions a batch
+    // ahead, keeps the reset stock and stores the first record plane): the families whose physics and reward waves are
+    // comparable once the draw is off them (measured at 1 024 .. 65 536 envs, profiles/r03_table_variants.txt: QQube -16 %,
+    // oscillator / pendulum -10 .. -20 %; ball-on-beam, cartpole and ball balancer, whose physics wave is the long one by
+    // itself, gain nothing and keep two waves)
+    static constexpr bool WS_G3 = false;
     // Env.limit_act -> BoxSpace.project_to (P/spaces/box.py:180-184); np.clip propagates NaN (fminf/fmaxf would drop it)
     template <class R>
     __device__ static void limit_act(const float*, const float* lo, const float* hi, const R* a_raw, R* a) {
@@ -261,6 +267,7 @@ struct Omo : EnvDefaults<1> {
     static constexpr int REW = REW_QUADR, RADIAL = -1, CMAX = -1;
     static constexpr int FINAL = FINAL_CONST_MALUS;  // FinalRewTask(factor 1e3, always_negative), :75-79
     static constexpr bool WS_DRAW_P = true;  // a two-instruction physics step: the reward / record wave is the long one
+    static constexpr bool WS_G3 = true;
     // (WS_PAYS: with its batch loops unrolled the split pays even for this small step: +8 % with records, +5 % without)
     enum { C_A10, C_A11, C_B1, C_AMAX };
     __device__ static void calc_consts(const Task&, const float* p, float* c) {  // _calc_constants :88-103
@@ -395,6 +402,7 @@ struct QQT : EnvDefaults<1> {
     static constexpr int REW = REW_EXP, RADIAL = 1, CMAX = -1;
     static constexpr bool REWARD_SIDE_USES_CONSTS = false;
     static constexpr bool WS_DRAW_P = true;
+    static constexpr bool WS_G3 = true;
     enum { C_C0, C_C1, C_C2, C_C3, C_C4, C_KM, C_RM, C_DR, C_DP, C_TH_NEG, C_TH_POS };
     __device__ static void calc_consts(const Task&, const float* p, float* c) {  // _calc_constants :70-87
         float g = p[0], Rm = p[1], km = p[2], mr = p[3], Lr = p[4], Dr = p[5], mp = p[6], Lp = p[7], Dp = p[8];
@@ -628,6 +636,7 @@ struct Pend : EnvDefaults<1> {
     // idcs=[1] in the reference (pendulum.py:87): the 2pi modulo is applied to the theta_dot error
     static constexpr int REW = REW_EXP, RADIAL = 1, CMAX = -1;
     static constexpr bool WS_DRAW_P = true;
+    static constexpr bool WS_G3 = true;
     enum { C_MGL2, C_DAMP, C_INV_J, C_AMAX };
     __device__ static void calc_consts(const Task&, const float* p, float* c) {
         float g = p[0], m = p[1], l = p[2];

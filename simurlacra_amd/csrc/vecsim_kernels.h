@@ -92,7 +92,7 @@ struct Dev {
     int traj_rows;  // capacity of the record buffers in rows
     int* rec_row;   // device-side row counter of vs_step_record(row < 0), advanced by k_bump_row
     float *jac_s, *jac_r, *jac_o;  // step Jacobians (vs_step_jac), allocated on first use
-    unsigned long long* dbg;       // diagnostic builds only (-DVS_WS_STAMP): per-wave cycle sums, [ld / 64][2 roles][4]
+    unsigned long long* dbg;       // diagnostic builds only (-DVS_WS_STAMP): per-wave cycle sums, [ld / 64][3 roles][4]
     int n, ld;
 };
 
@@ -417,9 +417,11 @@ template <int F>
 struct Planes {
     static constexpr int NQ = F / 4, H2 = (F % 4) >= 2 ? 1 : 0, H1 = F % 2;
     // v[0 .. F) of env i into a row of planes with `ld` envs per plane (global memory or LDS)
+    template <int Q0 = 0>
     __device__ __forceinline__ static void store(float* __restrict__ row, size_t ld, int i, const float* v) {
+        static_assert(Q0 <= NQ, "first plane");
 #pragma unroll
-        for (int q = 0; q < NQ; ++q)
+        for (int q = Q0; q < NQ; ++q)
             reinterpret_cast<float4*>(row + (size_t)q * 4 * ld)[i] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
         if (H2) reinterpret_cast<float2*>(row + (size_t)NQ * 4 * ld)[i] = make_float2(v[4 * NQ], v[4 * NQ + 1]);
         if (H1) row[((size_t)NQ * 4 + H2 * 2) * ld + i] = v[F - 1];
@@ -446,7 +448,8 @@ struct Rec {
     static constexpr int F = REC == 2 ? E::O + E::A + 1 + E::S + E::A + E::H : E::O + E::A + 1;
 };
 // s_pre / a_app / h_pre are read for REC == 2 only
-template <class E, int REC>
+// Q0: first 4-float plane to store (1: plane 0 is written by another wave, see k_rollout_ws's generator wave)
+template <class E, int REC, int Q0 = 0>
 __device__ __forceinline__ void store_record(float* __restrict__ row, size_t ld, int i, const float* ob, const float* a,
                                              float rew, const float* s_pre, const float* a_app, const float* h_pre) {
     constexpr int F = Rec<E, REC>::F;
@@ -465,7 +468,7 @@ __device__ __forceinline__ void store_record(float* __restrict__ row, size_t ld,
 #pragma unroll
         for (int j = 0; j < E::H; ++j) v[B + E::S + E::A + j] = h_pre[j];
     }
-    Planes<F>::store(row, ld, i, v);
+    Planes<F>::template store<Q0>(row, ld, i, v);
 }
 
 // done flags of the recorded steps: one bit per env and step, 32 steps to a word, words [t / 32][ld] -- a lane keeps the
@@ -865,11 +868,20 @@ __device__ __forceinline__ void ws_barrier() {
 // DP ("draw on P"): the policy's action generator runs on the physics wave and the action travels in the message instead of
 // through l_act -- for the families whose C wave is the longer one once it records (QQube: its share of observe() plus the
 // record stores outweigh the Philox block per four steps; measured with the per-role cycle stamps of -DVS_WS_STAMP).
-template <class E, bool UNI, bool AR, int REC, int WS_R, int NE, bool DP>
-__global__ __launch_bounds__(2 * NE) void k_rollout_ws(Task T, Dev d, int k_steps, uint64_t seed, uint64_t reset_seed,
-                                                       uint64_t epoch0) {
+template <class E, bool UNI, bool AR, int REC, int WS_R, int NE, bool DP, int NR = 2>
+__global__ __launch_bounds__(NR * NE, NR == 3 ? 3 : 1) void k_rollout_ws(Task T, Dev d, int k_steps, uint64_t seed, uint64_t reset_seed,
+                                                        uint64_t epoch0) {
     static_assert(E::FINAL != FINAL_STATE_TIME, "needs the post-step state on the reward side");
     static_assert(NE == 64 || NE == 128 || NE == 256, "envs per workgroup");
+    static_assert(NR == 2 || (NR == 3 && !DP), "two roles, or three with the generator wave drawing the actions");
+    // GOBS: the generator wave (NR == 3) also finishes the observation and stores the record's first plane (the first four
+    // observation floats); the C wave then stores the remaining planes only
+    constexpr bool G3 = NR == 3;
+#ifdef VS_G_NOOBS  // diagnostic builds only
+    constexpr bool GOBS = false;
+#else
+    constexpr bool GOBS = G3 && REC != 0 && E::O >= 4;
+#endif
     // DP draws a batch of actions ahead with the action bounds of that moment: fine, because the bounds change only with a
     // redraw of the domain parameters at a reset, and a family whose bounds depend on them (REWARD_SIDE_USES_CONSTS) never
     // runs this kernel under live randomisation (Launch<E>::variant)
@@ -886,7 +898,10 @@ __global__ __launch_bounds__(2 * NE) void k_rollout_ws(Task T, Dev d, int k_step
     constexpr bool PC = PCL > 0;
     static_assert(PCL != 2 || E::REWARD_SIDE_USES_CONSTS, "a dead zone on the C wave reads per-env constants");
     constexpr int AW = PC ? 2 * E::A : E::A;  // floats per step in l_act: [u | a] or [a]
-    __shared__ __attribute__((aligned(16))) float l_act[DP ? 1 : 2][DP ? 1 : WS_R][DP ? 4 : AW * NE];
+    // two buffers (the C wave draws batch b + 1 after it has worked batch b - 1 off), three when a wave of its own draws:
+    // in phase b the G wave writes batch b + 1 while P reads batch b and C still reads the raw actions of batch b - 1
+    __shared__ __attribute__((aligned(16))) float l_act[G3 ? 3 : (DP ? 1 : 2)][DP ? 1 : WS_R][DP ? 4 : AW * NE];
+    auto ab = [](int bb) __attribute__((always_inline)) { return DP ? 0 : (G3 ? bb % 3 : (bb & 1)); };
     // The reset stock (auto-reset only): the C wave keeps, per lane, the init-space sample of the lane's NEXT episode (and
     // the trig of that state) ready in LDS, tagged with the episode counter it was drawn for.  A resetting lane of the P
     // wave takes it with a handful of LDS reads instead of running Philox + sample_init + observe_p for the one or two
@@ -899,9 +914,10 @@ __global__ __launch_bounds__(2 * NE) void k_rollout_ws(Task T, Dev d, int k_step
     constexpr int WS_REFILL = 8;
     __shared__ float l_stock[STOCK ? SKW * NE : 1];
     __shared__ uint32_t l_stag[STOCK ? NE : 1];
+    __shared__ uint32_t l_epi[(STOCK && G3) ? NE : 1];  // G3: the P wave publishes a lane's episode counter at its resets
     const bool stock_on = STOCK && d.dr_n == 0 && d.pbuf_n == 0;  // wave-uniform
     const int wave = threadIdx.x >> 6;
-    const bool role_c = wave >= NE / 64;
+    const int role = wave / (NE / 64);  // 0 P, 1 C, 2 G (NR == 3)
     const int le = threadIdx.x & (NE - 1);  // env slot inside the workgroup
     const int i = blockIdx.x * NE + le;
     const size_t ld = d.ld;
@@ -962,7 +978,41 @@ __global__ __launch_bounds__(2 * NE) void k_rollout_ws(Task T, Dev d, int k_step
         }
     };
 
-    if (!role_c) {
+    // The stock refill and the draw into l_act: run by the C wave, or by the G wave when there is one (NR == 3).
+    uint32_t c_epi = 0u;           // the lane's episode counter as the refilling wave has seen it advance
+    uint32_t c_tag = 0xFFFFFFFFu;  // the counter the lane's stock entry was drawn for (none yet)
+    auto refill = [&]() __attribute__((always_inline)) {
+        if (!STOCK) return;
+        if (G3) c_epi = __hip_atomic_load(&l_epi[le], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const bool need = stock_on && valid && c_tag != c_epi;
+        if (__builtin_amdgcn_ballot_w64(need) == 0ull) return;
+        if (need) {
+            // SimPyEnv.reset's init_space.sample_uniform() of episode c_epi: the draw reset_lane_sampled would make
+            Rng g(reset_seed, d.idx0 + (uint32_t)i, RNG_INIT, (uint64_t)c_epi);
+            float init[E::I];
+            E::sample_init(T, c, g, init);
+#pragma unroll
+            for (int j = 0; j < E::I; ++j) l_stock[j * NE + le] = init[j];
+            if (REC && E::TRIG > 0) {
+                float s0[E::S], tr0[NT];
+                E::state_from_init(init, s0);
+                E::observe_p(s0, tr0);
+#pragma unroll
+                for (int j = 0; j < E::TRIG; ++j) l_stock[(E::I + j) * NE + le] = tr0[j];
+            }
+            __hip_atomic_store(&l_stag[le], c_epi, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            c_tag = c_epi;
+        }
+    };
+    auto draw = [&](int bb) __attribute__((always_inline)) {
+        if (DP) return;
+        float a_new[WS_R][AW];
+        draw_batch(bb, a_new);
+#pragma unroll
+        for (int r = 0; r < WS_R; ++r) Planes<AW>::store(l_act[ab(bb)][DP ? 0 : r], NE, le, a_new[r]);
+    };
+
+    if (role == 0) {
         // ------------------------------------------------------------------------------------------- P wave
         float s[E::S], h[NH], tr[NT], ob[E::O];
 #pragma unroll
@@ -988,7 +1038,7 @@ __global__ __launch_bounds__(2 * NE) void k_rollout_ws(Task T, Dev d, int k_step
                 draw_batch(b, a_all);
             } else {
 #pragma unroll
-                for (int r = 0; r < WS_R; ++r) Planes<AW>::load(l_act[b & 1][r], NE, le, a_all[r]);
+                for (int r = 0; r < WS_R; ++r) Planes<AW>::load(l_act[ab(b)][DP ? 0 : r], NE, le, a_all[r]);
             }
 #pragma unroll
             for (int r = 0; r < WS_R; ++r) {
@@ -1080,6 +1130,9 @@ __global__ __launch_bounds__(2 * NE) void k_rollout_ws(Task T, Dev d, int k_step
                             }
                             epi += 1u;
                             step = 0;
+                            // (after the reads of the stock entry above: the G wave rewrites an entry only once it has seen
+                            // a counter beyond the entry's tag)
+                            if (STOCK && G3) __hip_atomic_store(&l_epi[le], epi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         }
                         if (!UNI) E::act_bounds(c, alo, ahi);
                     }
@@ -1109,7 +1162,7 @@ __global__ __launch_bounds__(2 * NE) void k_rollout_ws(Task T, Dev d, int k_step
         }
 #ifdef VS_WS_STAMP
         if ((threadIdx.x & 63) == 0 && d.dbg) {
-            unsigned long long* q = d.dbg + ((size_t)(i >> 6) * 2 + 0) * 4;
+            unsigned long long* q = d.dbg + ((size_t)(i >> 6) * 3 + 0) * 4;
             q[0] = acc0, q[1] = acc1, q[2] = acc2, q[3] = (unsigned long long)nb;
         }
 #endif
@@ -1127,7 +1180,7 @@ __global__ __launch_bounds__(2 * NE) void k_rollout_ws(Task T, Dev d, int k_step
         d.ep_idx[i] = epi;
         d.done[i] = done;
         d.failed[i] = failed;
-    } else {
+    } else if (role == 1) {
         // ------------------------------------------------------------------------------------------- C wave
         const size_t rec0 = (size_t)d.traj_t0;
         float ret = d.ret[i];
@@ -1137,39 +1190,11 @@ __global__ __launch_bounds__(2 * NE) void k_rollout_ws(Task T, Dev d, int k_step
         int len = d.step[i];
         DoneBits db;
         if (REC) db.begin(d, i, rec0);
-        uint32_t c_epi = STOCK ? d.ep_idx[i] : 0u;  // the lane's episode counter as this side has seen it advance
-        uint32_t c_tag = 0xFFFFFFFFu;               // the counter the lane's stock entry was drawn for (none yet)
-        if (STOCK) l_stag[le] = 0xFFFFFFFFu;
-        auto refill = [&]() __attribute__((always_inline)) {
-            if (!STOCK) return;
-            const bool need = stock_on && valid && c_tag != c_epi;
-            if (__builtin_amdgcn_ballot_w64(need) == 0ull) return;
-            if (need) {
-                // SimPyEnv.reset's init_space.sample_uniform() of episode c_epi: the draw reset_lane_sampled would make
-                Rng g(reset_seed, d.idx0 + (uint32_t)i, RNG_INIT, (uint64_t)c_epi);
-                float init[E::I];
-                E::sample_init(T, c, g, init);
-#pragma unroll
-                for (int j = 0; j < E::I; ++j) l_stock[j * NE + le] = init[j];
-                if (REC && E::TRIG > 0) {
-                    float s0[E::S], tr0[NT];
-                    E::state_from_init(init, s0);
-                    E::observe_p(s0, tr0);
-#pragma unroll
-                    for (int j = 0; j < E::TRIG; ++j) l_stock[(E::I + j) * NE + le] = tr0[j];
-                }
-                __hip_atomic_store(&l_stag[le], c_epi, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                c_tag = c_epi;
-            }
-        };
-        if (!DP) carry = Rng::philox(seed, d.idx0 + (uint32_t)i, RNG_ACT, blk0);
-        auto draw = [&](int bb) __attribute__((always_inline)) {
-            if (DP) return;
-            float a_new[WS_R][AW];
-            draw_batch(bb, a_new);
-#pragma unroll
-            for (int r = 0; r < WS_R; ++r) Planes<AW>::store(l_act[DP ? 0 : (bb & 1)][DP ? 0 : r], NE, le, a_new[r]);
-        };
+        if (STOCK && !G3) {
+            c_epi = d.ep_idx[i];
+            l_stag[le] = 0xFFFFFFFFu;
+        }
+        if (!DP && !G3) carry = Rng::philox(seed, d.idx0 + (uint32_t)i, RNG_ACT, blk0);
         // Reward, returns and records of the steps of batch bb, in three passes so that the arithmetic of the WS_R steps --
         // independent of each other -- sits in ONE basic block (instruction-level parallelism for a wave that otherwise
         // waits on its own dependent chains), the per-step bookkeeping with its rare branches in the second, the stores last.
@@ -1185,11 +1210,11 @@ __global__ __launch_bounds__(2 * NE) void k_rollout_ws(Task T, Dev d, int k_step
                     for (int j = 0; j < E::A; ++j) a[r][j] = v[r][AM0 + j];
                 } else if (PC) {
                     float ua[AW];
-                    Planes<AW>::load(l_act[DP ? 0 : (bb & 1)][DP ? 0 : r], NE, le, ua);
+                    Planes<AW>::load(l_act[ab(bb)][DP ? 0 : r], NE, le, ua);
 #pragma unroll
                     for (int j = 0; j < E::A; ++j) a[r][j] = ua[E::A + j];
                 } else {
-                    Planes<E::A>::load(l_act[DP ? 0 : (bb & 1)][DP ? 0 : r], NE, le, a[r]);
+                    Planes<E::A>::load(l_act[ab(bb)][DP ? 0 : r], NE, le, a[r]);
                 }
             }
 #pragma unroll
@@ -1253,8 +1278,8 @@ __global__ __launch_bounds__(2 * NE) void k_rollout_ws(Task T, Dev d, int k_step
                 for (int r = 0; r < WS_R; ++r) {
                     if (!FULL && r >= nr) continue;
                     const int t = bb * WS_R + r;
-                    store_record<E, REC>(d.traj_rec + (rec0 + (size_t)t) * Rec<E, REC>::F * ld, ld, i, ob[r], a[r], rw[r], v[r],
-                                         a_app[r], v[r] + HM0);
+                    store_record<E, REC, GOBS ? 1 : 0>(d.traj_rec + (rec0 + (size_t)t) * Rec<E, REC>::F * ld, ld, i, ob[r], a[r], rw[r],
+                                                       v[r], a_app[r], v[r] + HM0);
                     db.put(d, i, rec0 + (size_t)t, dn[r], t == k_steps - 1);
                 }
             }
@@ -1265,7 +1290,7 @@ __global__ __launch_bounds__(2 * NE) void k_rollout_ws(Task T, Dev d, int k_step
             else work_off(std::false_type{}, bb, nr);
         };
         __builtin_amdgcn_s_waitcnt(0x0F70);
-        draw(0);
+        if (!G3) draw(0);
         ws_barrier();
 #ifdef VS_WS_NOC  // diagnostic: the C wave only keeps the barriers
         for (int b = 0; b < nb; ++b) ws_barrier();
@@ -1278,10 +1303,12 @@ __global__ __launch_bounds__(2 * NE) void k_rollout_ws(Task T, Dev d, int k_step
             VS_STAMP(st0);
             if (b >= 1) work(b - 1);  // reads l_act[(b - 1) & 1] before draw(b + 1) overwrites the same buffer
             VS_STAMP(st1);
-            if (b + 1 < nb) draw(b + 1);
-            // (b == 0 fills every lane's first entry while this wave has no batch to work off yet: a lane of P that resets
-            // before its entry is there draws for itself)
-            if ((b & (WS_REFILL - 1)) == 0) refill();
+            if (!G3) {
+                if (b + 1 < nb) draw(b + 1);
+                // (b == 0 fills every lane's first entry while this wave has no batch to work off yet: a lane of P that
+                // resets before its entry is there draws for itself)
+                if ((b & (WS_REFILL - 1)) == 0) refill();
+            }
             VS_STAMP(st2);
             ws_barrier();
 #ifdef VS_WS_STAMP
@@ -1291,7 +1318,7 @@ __global__ __launch_bounds__(2 * NE) void k_rollout_ws(Task T, Dev d, int k_step
         }
 #ifdef VS_WS_STAMP
         if ((threadIdx.x & 63) == 0 && d.dbg) {
-            unsigned long long* q = d.dbg + ((size_t)(i >> 6) * 2 + 1) * 4;
+            unsigned long long* q = d.dbg + ((size_t)(i >> 6) * 3 + 1) * 4;
             q[0] = acc0, q[1] = acc1, q[2] = acc2, q[3] = (unsigned long long)nb;
         }
 #endif
@@ -1302,6 +1329,67 @@ __global__ __launch_bounds__(2 * NE) void k_rollout_ws(Task T, Dev d, int k_step
         d.es_count[i] = es.count;
         d.es_retsum[i] = es.retsum;
         d.es_lensum[i] = es.lensum;
+    } else {
+        // ------------------------------------------------------------------------------------------- G wave (NR == 3)
+        // The generator: everything that does not wait for the physics -- the policy's actions a batch ahead (with their
+        // pre-processing when E::WS_PREP_C), the reset stock -- and, GOBS, the first plane of the records: it reads the
+        // messages of batch b - 1 like the C wave, finishes the observation (E::observe_c) and stores its first four floats.
+        if constexpr (G3) {
+            const size_t rec0 = (size_t)d.traj_t0;
+            if (STOCK) {
+                c_epi = d.ep_idx[i];
+                l_stag[le] = 0xFFFFFFFFu;
+                l_epi[le] = c_epi;
+            }
+            carry = Rng::philox(seed, d.idx0 + (uint32_t)i, RNG_ACT, blk0);
+            auto obs_off = [&](auto full_tag, int bb, int nr) __attribute__((always_inline)) {
+                constexpr bool FULL = decltype(full_tag)::value;
+                // step by step (load -> observe_c -> store): this wave is not the long one, and four steps' worth of messages
+                // and observations held at once pushed the kernel past the 168 VGPRs three waves per SIMD allow
+#pragma unroll
+                for (int r = 0; r < WS_R; ++r) {
+                    if (!FULL && r >= nr) continue;
+                    float v[M], ob[E::O];
+                    Planes<M>::load(l_msg[bb & 1][r], NE, le, v);
+                    E::observe_c(v, v + TR0, ob);
+                    const int t = bb * WS_R + r;
+                    float* row = d.traj_rec + (rec0 + (size_t)t) * Rec<E, REC>::F * ld;
+                    reinterpret_cast<float4*>(row)[i] = make_float4(ob[0], ob[1], ob[2], ob[3]);
+                }
+            };
+            auto obs_work = [&](int bb) __attribute__((always_inline)) {
+                if (!GOBS) return;
+                const int nr = min(WS_R, k_steps - bb * WS_R);
+                if (nr == WS_R) obs_off(std::true_type{}, bb, nr);
+                else obs_off(std::false_type{}, bb, nr);
+            };
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            draw(0);
+            ws_barrier();
+#ifdef VS_WS_STAMP
+            unsigned long long acc0 = 0, acc1 = 0, acc2 = 0;
+#endif
+            for (int b = 0; b < nb; ++b) {
+                VS_STAMP(st0);
+                if (b + 1 < nb) draw(b + 1);  // into l_act[(b + 1) % 3]: P reads b % 3, C (b - 1) % 3
+                if ((b & (WS_REFILL - 1)) == 0) refill();
+                VS_STAMP(st1);
+                if (b >= 1) obs_work(b - 1);
+                VS_STAMP(st2);
+                ws_barrier();
+#ifdef VS_WS_STAMP
+                VS_STAMP(st3);
+                acc0 += st1 - st0, acc1 += st2 - st1, acc2 += st3 - st2;
+#endif
+            }
+#ifdef VS_WS_STAMP
+            if ((threadIdx.x & 63) == 0 && d.dbg) {
+                unsigned long long* q = d.dbg + ((size_t)(i >> 6) * 3 + 2) * 4;
+                q[0] = acc0, q[1] = acc1, q[2] = acc2, q[3] = (unsigned long long)nb;
+            }
+#endif
+            obs_work(nb - 1);
+        }
     }
 }
 
@@ -1473,7 +1561,7 @@ struct vs_env {
     vs::DrSpecs* d_specs = nullptr;   // device scratch for vs_sample_params
     float* d_pbuf = nullptr;      // DomainRandWrapperBuffer parameter sets
     float* d_ring = nullptr;      // ActDelayWrapper ring (Pipe::ring)
-    int rollout_variant = -1;     // vs_set_rollout_variant: -1 automatic, 0 k_rollout, 1 k_rollout_ws<256>, 2 k_rollout_ws<64>
+    int rollout_variant = -1;     // vs_set_rollout_variant: -1 automatic, 0 k_rollout, 1 k_rollout_ws<256>, 2 k_rollout_ws<64>, 3 / 4 the three-role kernel in 64 / 256-env workgroups
     int n_cu = 256;               // compute units of the device (256 on MI355X)
     bool auto_reset = false;
     uint64_t ar_seed = 0;
@@ -1496,7 +1584,7 @@ namespace vs {
 
 static inline dim3 grid_for(int ld) { return dim3((unsigned)((ld + BLOCK - 1) / BLOCK)); }
 
-enum RolloutVariant { RV_PLAIN = 0, RV_WS256 = 1, RV_WS64 = 2 };
+enum RolloutVariant { RV_PLAIN = 0, RV_WS256 = 1, RV_WS64 = 2, RV_WS64G = 3, RV_WS256G = 4 };
 
 // per-family launchers: defined (explicitly instantiated) in vecsim_family.hip, one translation unit per family
 template <class E>
@@ -1528,19 +1616,31 @@ void launch_step_mixed(const Segs* dev_segs, int total_blocks, hipStream_t st, b
 //   * up to 384 envs per compute unit (98 304): 64-env workgroups still beat k_rollout's one-and-a-half waves per SIMD
 //     (QQube: 72 against 86 us per 100 recorded steps) where the kernel's registers allow a third wave per SIMD (E::WS_MID:
 //     not the cartpole's 224);
-//   * beyond: k_rollout has two or more waves per SIMD by itself.
-// VS_ROLLOUT_VARIANT=plain|ws|ws64 overrides for every handle (experiments); vs_set_rollout_variant pins per handle.
+//   * beyond: k_rollout has two or more waves per SIMD by itself;
+//   * the families with E::WS_G3 (QQube, oscillator, pendulum) run THREE waves per 64 envs up to 256 envs per compute unit
+//     (profiles/r03_table_variants.txt: QQube at 65 536 envs 44.8 -> 37.7 us, at 4 096 envs 32.7 -> 27.1 us per 100 steps).
+// VS_ROLLOUT_VARIANT=plain|ws|ws64|g64|g256 overrides for every handle (experiments); vs_set_rollout_variant pins per handle.
 template <class E>
 int Launch<E>::variant(vs_env* h) {
     if (E::FINAL == FINAL_STATE_TIME) return RV_PLAIN;
     if (h->d.pipe.act_on || h->d.pipe.obs_on) return RV_PLAIN;
     const bool live = h->dr.n > 0 || h->d.pbuf_n > 0;
     if (live && E::REWARD_SIDE_USES_CONSTS) return RV_PLAIN;
-    if (h->rollout_variant >= 0) return h->rollout_variant;
+    // the three-role shapes exist for the families they pay for (E::WS_G3); elsewhere a pin falls back to the two-role shape
+    auto have = [](int v) { return E::WS_G3 ? v : (v == RV_WS64G ? (int)RV_WS64 : v == RV_WS256G ? (int)RV_WS256 : v); };
+    if (h->rollout_variant >= 0) return have(h->rollout_variant);
     static const char* force = getenv("VS_ROLLOUT_VARIANT");
     if (force && force[0] == 'p') return RV_PLAIN;
     if (force && force[0] == 'w') return force[1] && force[2] == '6' ? RV_WS64 : RV_WS256;
+    if (force && force[0] == 'g') return have(force[1] == '6' ? RV_WS64G : RV_WS256G);  // g64 | g256
     const int64_t ld = h->d.ld, cu = h->n_cu;
+    if (E::WS_G3) {
+        // three waves per 64 envs: 64-env workgroups up to 128 envs per compute unit (and under a live randomizer, where a
+        // redraw then stalls one trio of waves instead of four), 256-env workgroups (one per CU, a wave of each role on every
+        // SIMD) up to 256; beyond that the two-role shape has its third wave per SIMD from the envs themselves
+        if (ld <= 128 * cu) return RV_WS64G;
+        if (ld <= 256 * cu) return live ? RV_WS64G : RV_WS256G;
+    }
     if (ld <= E::WS_SMALL * cu) return RV_WS64;
     if (!E::WS_PAYS) return RV_PLAIN;
     if (ld <= 256 * cu) return live ? RV_WS64 : (E::WS_SHAPE_FULL == 64 ? RV_WS64 : RV_WS256);
@@ -1567,12 +1667,12 @@ void Launch<E>::step(vs_env* h, const float* act, long es, long ds, int rec, int
     else launch_step_rec<E, 2>(h, act, es, ds, row);
 }
 
-template <class E, bool U, bool AR, int NE>
+template <class E, bool U, bool AR, int NE, int NR = 2>
 static void launch_ws(vs_env* h, int k, uint64_t seed, uint64_t ep, int rec) {
     if constexpr (E::FINAL != FINAL_STATE_TIME) {
-        dim3 g((unsigned)(h->d.ld / NE)), b(2 * NE);
+        dim3 g((unsigned)(h->d.ld / NE)), b(NR * NE);
         // R = 4 steps per exchange (measured on the headline config: R = 1 / 2 / 4 -> 68.7 / 64.8 / 62.0 us per 100 steps)
-#define LW(REC) hipLaunchKernelGGL((k_rollout_ws<E, U, AR, REC, 4, NE, (E::WS_DRAW_P && REC != 0)>), g, b, 0, h->stream, h->task, h->d, k, seed, h->ar_seed, ep)
+#define LW(REC) hipLaunchKernelGGL((k_rollout_ws<E, U, AR, REC, 4, NE, (NR == 2 && E::WS_DRAW_P && REC != 0), NR>), g, b, 0, h->stream, h->task, h->d, k, seed, h->ar_seed, ep)
         if (rec == 0) LW(0); else if (rec == 1) LW(1); else LW(2);
 #undef LW
     }
@@ -1591,11 +1691,15 @@ void Launch<E>::rollout(vs_env* h, int k, uint64_t seed, uint64_t ep, int rec) {
     const bool uni = h->uniform && h->dr.n == 0;
     const bool ar = h->auto_reset;
     const int var = variant(h);
-    if (var == RV_WS256 || var == RV_WS64) {
-#define WS(NE)                                                                                     \
-    if (uni) { if (ar) launch_ws<E, true, true, NE>(h, k, seed, ep, rec); else launch_ws<E, true, false, NE>(h, k, seed, ep, rec); } \
-    else { if (ar) launch_ws<E, false, true, NE>(h, k, seed, ep, rec); else launch_ws<E, false, false, NE>(h, k, seed, ep, rec); }
-        if (var == RV_WS64) { WS(64) } else { WS(256) }
+    if (var != RV_PLAIN) {
+#define WS(NE, NR)                                                                                     \
+    if (uni) { if (ar) launch_ws<E, true, true, NE, NR>(h, k, seed, ep, rec); else launch_ws<E, true, false, NE, NR>(h, k, seed, ep, rec); } \
+    else { if (ar) launch_ws<E, false, true, NE, NR>(h, k, seed, ep, rec); else launch_ws<E, false, false, NE, NR>(h, k, seed, ep, rec); }
+        if constexpr (E::WS_G3) {
+            if (var == RV_WS64G) { WS(64, 3) return; }
+            if (var == RV_WS256G) { WS(256, 3) return; }
+        }
+        if (var == RV_WS64 || var == RV_WS64G) { WS(64, 2) } else { WS(256, 2) }
 #undef WS
         return;
     }

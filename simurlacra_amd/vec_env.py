@@ -403,7 +403,7 @@ class VecSimEnv:
         self._check(self._lib.vs_set_traj_offset(self._h, int(t0)), "vs_set_traj_offset")
         self._traj_t0 = int(t0)
 
-    _VARIANTS = {None: -1, "k_rollout": 0, "k_rollout_ws": 1, "k_rollout_ws64": 2}
+    _VARIANTS = {None: -1, "k_rollout": 0, "k_rollout_ws": 1, "k_rollout_ws64": 2, "k_rollout_ws64g": 3, "k_rollout_ws256g": 4}
 
     def set_rollout_variant(self, variant=None):
         """None: automatic; 'k_rollout' / 'k_rollout_ws' (256-env workgroups) / 'k_rollout_ws64' (64-env workgroups) pin the
@@ -412,7 +412,7 @@ class VecSimEnv:
 
     def rollout_variant(self):
         """the kernel vs_step_random launches for the current configuration"""
-        return {0: "k_rollout", 1: "k_rollout_ws", 2: "k_rollout_ws64"}[self._lib.vs_rollout_variant(self._h)]
+        return {0: "k_rollout", 1: "k_rollout_ws", 2: "k_rollout_ws64", 3: "k_rollout_ws64g", 4: "k_rollout_ws256g"}[self._lib.vs_rollout_variant(self._h)]
 
     def traj_layout(self, mode=None):
         """(F, nq, h2, h1): a record is F floats -- mode 1: [obs | act | rew], mode 2: + [state | act_app | hidden] --

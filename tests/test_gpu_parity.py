@@ -45,6 +45,16 @@ def vs():
 
     return simurlacra_amd
 
+# the families that also run the three-role shapes of k_rollout_ws (E::WS_G3: a generator wave beside the physics and the
+# reward wave); pinning those shapes for another family falls back to the two-role shape of the same workgroup size
+G3_FAMILIES = {"qq-su", "qq-st", "omo", "pend"}
+
+
+def ws_variants(name):
+    base = ("k_rollout_ws", "k_rollout_ws64")
+    return base + (("k_rollout_ws64g", "k_rollout_ws256g") if name in G3_FAMILIES else ())
+
+
 
 def load(golden_dir, kind, name):
     return np.load(os.path.join(golden_dir, f"{kind}_{name.replace('-', '_')}.npz"))
@@ -884,7 +894,8 @@ def test_bernoulli_rounded_and_1d_multivariate_params_on_device(vs):
 @pytest.mark.parametrize("auto_reset", [False, True])
 @pytest.mark.parametrize("name", ["qq-su", "qcp-su", "bob", "omo", "qbb", "pend", "bob-d", "qq-st"])
 def test_wave_specialised_rollout_kernel_equals_plain_kernel(vs, name, auto_reset):
-    """k_rollout_ws (a physics wave + a reward/record wave per 64 envs, exchanging through LDS) against k_rollout: records,
+    """k_rollout_ws (a physics wave + a reward/record wave per 64 envs, exchanging through LDS; for QQube, the oscillator and
+    the pendulum also with a third, generator wave: actions a batch ahead, reset stock, first record plane) against k_rollout: records,
     final buffers, episode statistics and the episode log bit for bit; launches of 7, 1 and 30 steps (batches of 4 with a
     ragged tail), per-env and broadcast constants, n not a multiple of the 256-env workgroup"""
     L = vs._lib
@@ -896,7 +907,7 @@ def test_wave_specialised_rollout_kernel_equals_plain_kernel(vs, name, auto_rese
         if per_env == "live-dr" and not (auto_reset and name in live_dr):
             continue
         trio = []
-        for variant in ("k_rollout", "k_rollout_ws", "k_rollout_ws64"):
+        for variant in ("k_rollout",) + ws_variants(name):
             e = vs.VecSimEnv(name, n, **kw)
             e.set_record_mode(mode)
             if per_env is True:
@@ -978,15 +989,15 @@ def test_step_jacobians_against_the_forks_autograd(vs, golden_dir):
 
 def test_headline_launch_values_at_65536(vs):
     """The exact launch bench.py times -- 65 536 QQubeSwingUpSim envs, per-env constants, auto-reset, every step recorded,
-    bench.py's default steps per launch, k_rollout_ws in 64-env workgroups (four per compute unit) -- checked for VALUES:
-    records, final buffers and episode statistics equal the plain kernel's bit for bit (and the 256-env shape's), 512 lanes of the last
+    bench.py's default steps per launch, the three-role k_rollout_ws in 256-env workgroups (one per compute unit) -- checked for
+    VALUES: records, final buffers and episode statistics equal the plain kernel's bit for bit (and every other shape's), 512 lanes of the last
     recorded step are re-stepped by the fp64 oracle, and the record planes hold what rollout() keeps (mode 2)."""
     L = vs._lib
     import bench
 
     n, T = 65536, bench.DEFAULT_CHUNK
     trio = {}
-    for variant in ("k_rollout", "k_rollout_ws", "k_rollout_ws64"):
+    for variant in ("k_rollout",) + ws_variants("qq-su"):
         e = vs.VecSimEnv("qq-su", n, **KW["qq-su"])
         e.set_params(np.tile(vs.nominal_params("qq-su"), (n, 1)))
         e.set_rollout_variant(variant)
@@ -1000,11 +1011,11 @@ def test_headline_launch_values_at_65536(vs):
         e.step_random(T, seed=3, record=True)  # rows T .. 2T-1: a second launch continues the streams
         trio[variant] = e
     auto = vs.VecSimEnv("qq-su", n, **KW["qq-su"])
-    assert auto.rollout_variant() == "k_rollout_ws64"  # what the automatic choice (and bench.py) launches at this size
+    assert auto.rollout_variant() == "k_rollout_ws256g"  # what the automatic choice (and bench.py) launches at this size
     auto.close()
     a = trio["k_rollout"]
     tt_a = a.traj_tensors(2 * T)
-    for variant in ("k_rollout_ws", "k_rollout_ws64"):
+    for variant in ws_variants("qq-su"):
         b = trio[variant]
         tt_b = b.traj_tensors(2 * T)
         for key in ("rec", "done"):
@@ -1039,9 +1050,9 @@ def test_rollout_variant_selection(vs):
     faster shape at 256 -- and never with a wrapper pipeline, the state-and-time dependent final reward, or live
     randomisation of constants its reward wave reads"""
     e = vs.VecSimEnv("qq-su", 65536, **KW["qq-su"])
-    assert e.rollout_variant() == "k_rollout_ws64"
+    assert e.rollout_variant() == "k_rollout_ws256g"  # three waves per 64 envs, one workgroup per compute unit
     e.set_randomizer([("gravity_const", "normal", 9.81, 1.0, 1e-4, np.inf)])
-    assert e.rollout_variant() == "k_rollout_ws64"  # (a redraw stalls one pair of waves instead of four)
+    assert e.rollout_variant() == "k_rollout_ws64g"  # (a redraw stalls one trio of waves instead of four)
     e.set_rollout_variant("k_rollout_ws")
     assert e.rollout_variant() == "k_rollout_ws"
     e.set_rollout_variant(None)
@@ -1061,21 +1072,24 @@ def test_rollout_variant_selection(vs):
     e.set_act_pipeline(delay=0)
     assert e.rollout_variant() == "k_rollout_ws"  # the pin holds again
     e.set_rollout_variant(None)
-    assert e.rollout_variant() == "k_rollout_ws64"
+    assert e.rollout_variant() == "k_rollout_ws256g"
     e.close()
     for n_big, expect in ((65537, "k_rollout_ws64"), (98304, "k_rollout_ws64"), (98305, "k_rollout"), (131072, "k_rollout")):
         big = vs.VecSimEnv("qq-su", n_big, **KW["qq-su"])
         assert big.rollout_variant() == expect, n_big
         big.close()
-    for name, n, expect in (("omo", 4096, "k_rollout_ws64"), ("qbb", 4096, "k_rollout_ws64"), ("qbb", 32768, "k_rollout_ws64"),
+    for name, n, expect in (("omo", 4096, "k_rollout_ws64g"), ("qbb", 4096, "k_rollout_ws64"), ("qbb", 32768, "k_rollout_ws64"),
                             ("qbb", 65536, "k_rollout_ws"), ("qbb", 98304, "k_rollout"), ("qcp-st", 4096, "k_rollout"), ("bob", 65536, "k_rollout_ws"),
                             ("bob-d", 65536, "k_rollout_ws64"), ("bob", 98304, "k_rollout_ws64"), ("qcp-su", 65536, "k_rollout_ws"),
-                            ("qcp-su", 98304, "k_rollout"), ("qq-su", 4096, "k_rollout_ws64"), ("qq-su", 32768, "k_rollout_ws64"),
-                            ("omo", 65536, "k_rollout_ws64")):
+                            ("qcp-su", 98304, "k_rollout"), ("qq-su", 4096, "k_rollout_ws64g"), ("qq-su", 32768, "k_rollout_ws64g"),
+                            ("qq-su", 32769, "k_rollout_ws256g"), ("omo", 65536, "k_rollout_ws256g"), ("pend", 16384, "k_rollout_ws64g"),
+                            ("qq-st", 65536, "k_rollout_ws256g")):
         x = vs.VecSimEnv(name, n, **KW[name])
         assert x.rollout_variant() == expect, (name, n)
         x.set_rollout_variant("k_rollout_ws")
         assert x.rollout_variant() == ("k_rollout" if name == "qcp-st" else "k_rollout_ws")
+        x.set_rollout_variant("k_rollout_ws64g")  # the three-role shape only where the family has it
+        assert x.rollout_variant() == ("k_rollout" if name == "qcp-st" else "k_rollout_ws64g" if name in G3_FAMILIES else "k_rollout_ws64")
         x.close()
 
 
@@ -1126,7 +1140,7 @@ def test_fused_kernels_fuzz_against_step_kernel(vs):
         mode = int(rng.integers(1, 3))
         T = sum(splits)
         ref = vs.VecSimEnv(name, n, **kw, **extra)
-        envs = {v: vs.VecSimEnv(name, n, **kw, **extra) for v in ("k_rollout", "k_rollout_ws", "k_rollout_ws64")}
+        envs = {v: vs.VecSimEnv(name, n, **kw, **extra) for v in ("k_rollout",) + ws_variants(name)}
         params = None
         if per_env:
             params = np.tile(vs.nominal_params(name, **({"long": extra["long"]} if "long" in extra else {})), (n, 1))
@@ -1149,7 +1163,7 @@ def test_fused_kernels_fuzz_against_step_kernel(vs):
                 t += k
             trajs[v] = e.traj(T)
         a = trajs["k_rollout"]
-        for v in ("k_rollout_ws", "k_rollout_ws64"):
+        for v in ws_variants(name):
             for key in a:
                 assert np.array_equal(a[key], trajs[v][key]), (case, name, key, v)
         alive = np.ones(n, dtype=bool)
@@ -1174,8 +1188,10 @@ def test_fused_kernels_fuzz_against_step_kernel(vs):
             if not auto_reset:
                 alive &= ~a["done"][t].astype(bool)
         for which in (L.VS_STATE, L.VS_HIDDEN, L.VS_STEPCOUNT, L.VS_RETURNS):
-            x, y, z, w = (e.get(which) for e in (ref, envs["k_rollout"], envs["k_rollout_ws"], envs["k_rollout_ws64"]))
-            assert np.array_equal(y, z) and np.array_equal(y, w) and np.array_equal(x[alive], y[alive]), (case, name, which)
+            x, y = ref.get(which), envs["k_rollout"].get(which)
+            assert np.array_equal(x[alive], y[alive]), (case, name, which)
+            for v in ws_variants(name):
+                assert np.array_equal(y, envs[v].get(which)), (case, name, which, v)
         for e in [ref, *envs.values()]:
             assert e.error_count() == 0
             e.close()
@@ -1221,7 +1237,7 @@ def test_nan_flag_is_the_same_in_every_fused_kernel(vs, auto_reset):
     L = vs._lib
     n = 700
     flags = {}
-    for variant in ("k_rollout", "k_rollout_ws", "k_rollout_ws64"):
+    for variant in ("k_rollout",) + ws_variants("qq-su"):
         e = vs.VecSimEnv("qq-su", n, **dict(KW["qq-su"], max_steps=20))
         P = np.tile(vs.nominal_params("qq-su"), (n, 1))
         P[[5, 64, 699], 0] = np.nan
@@ -1251,7 +1267,7 @@ def test_long_launches_with_many_resets_equal_the_plain_kernel(vs, name):
     L = vs._lib
     n, T = 2048, 300
     out = {}
-    for variant in ("k_rollout", "k_rollout_ws", "k_rollout_ws64"):
+    for variant in ("k_rollout",) + ws_variants(name):
         e = vs.VecSimEnv(name, n, **dict(KW[name], max_steps=90))
         e.set_params(np.tile(vs.nominal_params(name), (n, 1)))
         e.set_rollout_variant(variant)
@@ -1268,7 +1284,7 @@ def test_long_launches_with_many_resets_equal_the_plain_kernel(vs, name):
     rec_a, done_a, fin_a = out["k_rollout"]
     assert int(done_a.sum()) >= 3 * n  # every lane finished (and restarted) several episodes
     gaps = torch.diff(torch.nonzero(done_a[:, 0]).flatten())
-    for variant in ("k_rollout_ws", "k_rollout_ws64"):
+    for variant in ws_variants(name):
         rec_b, done_b, fin_b = out[variant]
         assert torch.equal(rec_a, rec_b) and torch.equal(done_a, done_b), variant
         for w in fin_a:
