@@ -543,9 +543,10 @@ def roofline(args, env, local_rank, d, n, chunk, ms_region=None):
             del act
         except Exception as exc:  # the headline must not depend on this leg
             roof["large_n"] = {"error": repr(exc)}
-    roof["note"] = ("at 65 536 envs there is one wave of envs per SIMD: the fused kernel runs two cooperating waves per 64 envs "
-                    "(k_rollout_ws) and is bound by their dependent VALU issue (DESIGN.md sections 4 and 7), not by HBM; "
-                    "`large_n` is the HBM-bound point of the path") if args.mode == "fused" else \
+    roof["note"] = ("at 65 536 envs there is one wave of envs per SIMD: the fused kernel runs three cooperating waves per 64 envs "
+                    "(k_rollout_ws: physics | reward + records | action generator + first record plane); its record stream is a "
+                    "pure write stream, whose ceiling on this GPU is `write_kernel_GBs`, not the 8 TB/s of `peak` (DESIGN.md "
+                    "sections 4 and 7); `large_n` is the read + write HBM-bound point of the path") if args.mode == "fused" else \
                    ("one launch per env step; HBM-bound from ~1 M envs, launch-latency-bound at 65 536")
     return roof
 

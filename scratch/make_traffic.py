@@ -11,7 +11,7 @@ prof, out = sys.argv[1], sys.argv[2]
 def avg(dirname, counter, kernel):
     import os
     vals = []
-    kernel = {"k_rollout_ws64": "k_rollout_ws<"}.get(kernel, kernel)  # (the shape is a template argument of k_rollout_ws)
+    kernel = {"k_rollout_ws64": "k_rollout_ws<", "k_rollout_ws64g": "k_rollout_ws<", "k_rollout_ws256g": "k_rollout_ws<"}.get(kernel, kernel)  # (the shape is a template argument of k_rollout_ws)
     files = sorted(glob.glob(f"{prof}/{dirname}/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)
     for f in files[-1:]:  # the newest pass only (a merged output directory may hold an older run's files too)
         for row in csv.DictReader(open(f)):

@@ -200,7 +200,7 @@ struct Rng {
         return z0;
     }
 };
-enum RngPurpose { RNG_ACT = 1, RNG_INIT = 2, RNG_PARAM = 3, RNG_ACT_NOISE = 4, RNG_OBS_NOISE = 5 };
+enum RngPurpose { RNG_ACT = 1, RNG_INIT = 2, RNG_PARAM = 3, RNG_ACT_NOISE = 4, RNG_OBS_NOISE = 5, RNG_POLICY_NOISE = 6 };
 
 // defaults shared by the env structs (static members are inherited)
 enum FinalKind { FINAL_NONE = 0, FINAL_CONST_MALUS = 1, FINAL_STATE_TIME = 2 };
@@ -230,7 +230,7 @@ struct EnvDefaults {
     static constexpr bool WS_DRAW_P = false;
     // ... and whether a THIRD wave per 64 envs pays (k_rollout_ws with NR = 3: a generator wave draws the actions a batch
     // ahead, keeps the reset stock and stores the first record plane): the families whose physics and reward waves are
-    // comparable once the draw is off them (measured at 1 024 .. 65 536 envs, profiles/r03_table_variants.txt: QQube -16 %,
+    // comparable once the draw is off them (measured at 1 024 .. 65 536 envs, profiles/r02_table_three_roles.txt: QQube -16 %,
     // oscillator / pendulum -10 .. -20 %; ball-on-beam, cartpole and ball balancer, whose physics wave is the long one by
     // itself, gain nothing and keep two waves)
     static constexpr bool WS_G3 = false;

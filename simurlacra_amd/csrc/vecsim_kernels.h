@@ -417,14 +417,30 @@ template <int F>
 struct Planes {
     static constexpr int NQ = F / 4, H2 = (F % 4) >= 2 ? 1 : 0, H1 = F % 2;
     // v[0 .. F) of env i into a row of planes with `ld` envs per plane (global memory or LDS)
-    template <int Q0 = 0>
+    // NT: non-temporal stores (the record stream is written once and read by another kernel much later)
+    template <int Q0 = 0, bool NT = false>
     __device__ __forceinline__ static void store(float* __restrict__ row, size_t ld, int i, const float* v) {
         static_assert(Q0 <= NQ, "first plane");
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        typedef float f2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-        for (int q = Q0; q < NQ; ++q)
-            reinterpret_cast<float4*>(row + (size_t)q * 4 * ld)[i] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
-        if (H2) reinterpret_cast<float2*>(row + (size_t)NQ * 4 * ld)[i] = make_float2(v[4 * NQ], v[4 * NQ + 1]);
-        if (H1) row[((size_t)NQ * 4 + H2 * 2) * ld + i] = v[F - 1];
+        for (int q = Q0; q < NQ; ++q) {
+            f4 x = {v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+            f4* p = reinterpret_cast<f4*>(row + (size_t)q * 4 * ld) + i;
+            if (NT) __builtin_nontemporal_store(x, p);
+            else *p = x;
+        }
+        if (H2) {
+            f2 x = {v[4 * NQ], v[4 * NQ + 1]};
+            f2* p = reinterpret_cast<f2*>(row + (size_t)NQ * 4 * ld) + i;
+            if (NT) __builtin_nontemporal_store(x, p);
+            else *p = x;
+        }
+        if (H1) {
+            float* p = row + ((size_t)NQ * 4 + H2 * 2) * ld + i;
+            if (NT) __builtin_nontemporal_store(v[F - 1], p);
+            else *p = v[F - 1];
+        }
     }
     __device__ __forceinline__ static void load(const float* row, size_t ld, int i, float* v) {
 #pragma unroll
@@ -468,7 +484,8 @@ __device__ __forceinline__ void store_record(float* __restrict__ row, size_t ld,
 #pragma unroll
         for (int j = 0; j < E::H; ++j) v[B + E::S + E::A + j] = h_pre[j];
     }
-    Planes<F>::template store<Q0>(row, ld, i, v);
+    // non-temporal: +2 .. 6 % on every recording kernel (QQube 65 536 envs 1.63e11 -> 1.69e11, 1 M envs 1.11e11 -> 1.18e11)
+    Planes<F>::template store<Q0, true>(row, ld, i, v);
 }
 
 // done flags of the recorded steps: one bit per env and step, 32 steps to a word, words [t / 32][ld] -- a lane keeps the
@@ -827,6 +844,248 @@ __global__ __launch_bounds__(BLOCK) void k_rollout(Task T, Dev d, int k_steps, u
     rollout_body<E, UNI, AR, REC, PIPE>(T, d, k_steps, seed, reset_seed, epoch0, (int)blockIdx.x);
 }
 
+// LDS-only workgroup barrier of the multi-wave kernels below
+enum : unsigned { WSF_DONE = 1u, WSF_FAILED = 2u, WSF_FROZEN = 4u, WSF_FIN = 8u };
+
+__device__ __forceinline__ void ws_barrier() {
+#ifdef VS_WS_NOSYNC  // diagnostic builds only (timing without the exchange; results are wrong)
+    return;
+#endif
+    // LDS traffic only: wait for this wave's LDS ops (lgkmcnt(0)), not for its global stores (a __syncthreads() would also
+    // drain vmcnt and stall the C wave on its record stores in every phase)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// -------------------------------------------------------------------------------------------- policy inside the kernel
+// vs_step_policy: rollout() with a feed-forward network policy (P/policies/feed_back/fnn.py:43-160 FNN.forward, called at
+// rollout.py:203-219) evaluated INSIDE the fused rollout kernel -- k env steps per launch with a real policy in the loop and
+// no launch, no host round trip and no HBM traffic between the policy and the step.
+//   act = W_out f(... f(W_1 x + b_1) ...) + b_out  [output_nonlin]  [+ std * N(0, 1): NormalActNoiseExplStrat]
+//   x   = the observation rows the policy sees (ObsPartialWrapper: Fnn::obs_idx), optionally in the fork's featurisation
+//         [o_0, sin o_1, cos o_1, o_2 ..] (FNNPolicy.forward, fnn.py:219-222)
+// Shape of the work on CDNA4: one workgroup = 64 envs x FW waves.  The network of 64 envs is a [64 x in] x [in x 64] product
+// per layer with fp32 accuracy to keep (the policy's torch reference is fp32): every wave computes 64 / FW of a layer's 64
+// (zero-padded) units for all 64 envs -- lane = env, weights arrive as SCALAR loads (s_load_dwordx8: the row of a layer's
+// transposed, padded weight matrix is wave-uniform), activations are exchanged through LDS ([unit][lane]: conflict-free) with
+// one LDS-only barrier per layer.  Wave 0 additionally owns the envs: it writes the observation, evaluates the (narrow)
+// output layer, draws the exploration noise and runs the very step code of k_rollout (same records, same reset path).
+// fp32 FMAs on the vector ALU, not MFMA: the fp32 MFMA rate equals the vector rate on this chip and a 64-wide hidden layer
+// spread over 8 waves is 8 FMAs per input and wave; bf16 MFMA would change the policy's numerics.
+constexpr int FNN_MAXH = 4;  // hidden layers
+constexpr int FNN_W = 64;    // padded width of a hidden layer
+enum FnnNonlin { FNN_ID = 0, FNN_TANH = 1, FNN_RELU = 2, FNN_SIGMOID = 3 };
+struct Fnn {
+    const float* w;  // device, packed by vs_set_policy_fnn: per hidden layer l  Wt_l [in_l][64] (unit-contiguous rows, zero
+                     // padded) at off_w[l] and b_l [64] at off_b[l]; output layer  Wo [A][64] at off_w[n_hidden], bo [A]
+    int n_hidden, in_dim, out_dim;
+    int hidden[FNN_MAXH];
+    int hid_nonlin[FNN_MAXH], out_nonlin;
+    int feat;                 // 1: the fork's [o_0, sin o_1, cos o_1, o_2 ..] featurisation (in_dim = visible obs + 1)
+    int n_vis;                // number of observation rows the policy sees
+    int obs_idx[MAXO];        // ... and which they are
+    int ident;                // obs_idx is 0 .. O-1: the policy sees the whole observation
+    int noisy;                // any noise_std > 0
+    float noise_std[MAXA];
+    int off_w[FNN_MAXH + 1], off_b[FNN_MAXH + 1];
+};
+
+// tanh through v_exp_f32 / v_rcp_f32: (1 - t) / (1 + t), t = exp(-2|x|); absolute error < 2e-7 (the relative error grows
+// below |x| ~ 1e-3, where tanh x ~ x is tiny next to the biases it is added to); NaN stays NaN
+__device__ __forceinline__ float tanh_fast(float x) {
+    float t = __builtin_amdgcn_exp2f(-2.885390081777927f * fabsf(x));  // exp(-2|x|)
+    float r = (1.0f - t) * rcp_fast(1.0f + t);
+    return copysignf(r, x);
+}
+__device__ __forceinline__ float fnn_nonlin(int kind, float x) {  // kind is wave-uniform
+    if (kind == FNN_TANH) return tanh_fast(x);
+    if (kind == FNN_RELU) return fmaxf(x, 0.f);
+    if (kind == FNN_SIGMOID) return rcp_fast(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+    return x;
+}
+
+typedef const __attribute__((address_space(4))) float* cfloat_p;  // constant address space: loads are scalar (SMEM)
+
+template <class E, bool UNI, bool AR, int REC, int FW>
+__global__ __launch_bounds__(64 * FW) void k_rollout_fnn(Task T, Dev d, Fnn P, int k_steps, uint64_t reset_seed,
+                                                         uint64_t noise_seed) {
+    static_assert(FW == 1 || FW == 2 || FW == 4 || FW == 8, "waves per 64 envs");
+    constexpr int NJ = FNN_W / FW;  // hidden units per wave
+    __shared__ float l_x[2][FNN_W * 64];  // activations [unit][lane], ping-pong between layers
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 64 + lane;
+    const bool envw = wave == 0;  // the wave that owns the 64 envs
+    const size_t ld = d.ld;
+    const size_t rec0 = (size_t)d.traj_t0;
+    const bool valid = i < d.n;
+    const cfloat_p W = (cfloat_p)(uintptr_t)P.w;
+
+    // ---- env state of the lane: wave 0 only (the other waves never touch it)
+    float c[E::K], s[E::S], h[E::H > 0 ? E::H : 1], a[E::A], ob[E::O];
+    float alo[E::A], ahi[E::A];
+    int step = 0;
+    float ret = 0.f, rew = 0.f;
+    bool yielded = false, frozen = false, done = false, failed = false;
+    EpStat es{0u, 0u, 0.f, 0};
+    DoneBits db;
+    db.w = 0u;
+    if (envw) {
+        load_consts<E, UNI>(d, i, c, 0, E::KS);
+#pragma unroll
+        for (int j = 0; j < E::S; ++j) s[j] = d.state[j * ld + i];
+#pragma unroll
+        for (int j = 0; j < E::H; ++j) h[j] = d.hidden[j * ld + i];
+        step = d.step[i];
+        ret = d.ret[i];
+        yielded = E::FINAL != FINAL_NONE ? d.yielded[i] != 0 : false;
+        frozen = !AR && d.done[i] != 0;
+        rew = d.rew[i];
+        done = d.done[i] != 0, failed = d.failed[i] != 0;
+        es = EpStat{d.ep_idx[i], d.es_count[i], d.es_retsum[i], d.es_lensum[i]};
+        E::act_bounds(c, alo, ahi);
+        E::observe(s, ob);
+        if (REC) db.begin(d, i, rec0);
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // (see rollout_body: nothing pending at the loop header)
+    }
+
+    for (int t = 0; t < k_steps; ++t) {
+        // ---- input layer: what the policy sees of obs_t
+        if (envw) {
+            float x[MAXO + 1];
+            if (P.ident) {
+#pragma unroll
+                for (int k = 0; k < MAXO; ++k) x[k] = k < E::O ? ob[k] : 0.f;
+            } else {
+#pragma unroll
+                for (int k = 0; k < MAXO; ++k) {
+                    float v = 0.f;
+#pragma unroll
+                    for (int j = 0; j < E::O; ++j) v = (k < P.n_vis && P.obs_idx[k] == j) ? ob[j] : v;  // wave-uniform selects
+                    x[k] = v;
+                }
+            }
+            if (P.feat) {  // [o_0, sin o_1, cos o_1, o_2 ..]
+                float sn, cs;
+                sincos_fast(x[1], &sn, &cs);
+#pragma unroll
+                for (int k = MAXO; k >= 3; --k) x[k] = x[k - 1];
+                x[1] = sn, x[2] = cs;
+            } else {
+                x[MAXO] = 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k <= MAXO; ++k)
+                if (k < P.in_dim) l_x[0][k * 64 + lane] = x[k];
+        }
+        ws_barrier();
+        // ---- hidden layers: every wave, NJ units each
+        int n_in = P.in_dim, cur = 0;
+        for (int l = 0; l < P.n_hidden; ++l) {
+            const cfloat_p wl = W + P.off_w[l] + wave * NJ;
+            const cfloat_p bl = W + P.off_b[l] + wave * NJ;
+            float acc[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[j] = bl[j];
+            const float* xin = l_x[cur];
+#pragma unroll 4
+            for (int k = 0; k < n_in; ++k) {
+                const float xk = xin[k * 64 + lane];
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[j] = fmaf(wl[k * FNN_W + j], xk, acc[j]);
+            }
+            float* xout = l_x[cur ^ 1];
+            const int nl = P.hid_nonlin[l];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) xout[(wave * NJ + j) * 64 + lane] = fnn_nonlin(nl, acc[j]);
+            ws_barrier();
+            cur ^= 1;
+            n_in = P.hidden[l];
+        }
+        if (!envw) continue;
+        // ---- output layer + exploration noise: the policy's action
+        {
+            const cfloat_p wo = W + P.off_w[P.n_hidden];
+            const cfloat_p bo = W + P.off_b[P.n_hidden];
+            const float* xin = l_x[cur];
+#pragma unroll
+            for (int j = 0; j < E::A; ++j) a[j] = bo[j];
+#pragma unroll 4
+            for (int k = 0; k < n_in; ++k) {
+                const float xk = xin[k * 64 + lane];
+#pragma unroll
+                for (int j = 0; j < E::A; ++j) a[j] = fmaf(wo[j * FNN_W + k], xk, a[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < E::A; ++j) a[j] = fnn_nonlin(P.out_nonlin, a[j]);
+            if (P.noisy) {
+                // NormalActNoiseExplStrat: + std * N(0, 1), keyed like the wrapper noise by (env, episode, step)
+                uint4 b = Rng::philox(noise_seed, d.idx0 + (uint32_t)i, RNG_POLICY_NOISE, ((uint64_t)es.epi << 32) | (uint32_t)step);
+                float z[2];
+                Rng::box_muller(b.x, b.y, z[0], z[1]);
+#pragma unroll
+                for (int j = 0; j < E::A; ++j) a[j] = fmaf(P.noise_std[j], z[j], a[j]);
+            }
+        }
+        // ---- the env step: rollout_body's, statement for statement
+        float s_pre[E::S], h_pre[E::H > 0 ? E::H : 1], a_app[E::A], ow[E::O];
+#pragma unroll
+        for (int j = 0; j < E::O; ++j) ow[j] = ob[j];
+        if (REC == 2) {
+#pragma unroll
+            for (int j = 0; j < E::S; ++j) s_pre[j] = s[j];
+#pragma unroll
+            for (int j = 0; j < E::H; ++j) h_pre[j] = h[j];
+            applied_action<E>(T, c, alo, ahi, a, a_app);
+        }
+        if (!frozen) {
+            StepOut o = step_one<E, float>(T, c, s, h, a, step, yielded,
+                                           E::TRIG > 0 ? (const float*)(ob + E::TRIG_AT) : (const float*)nullptr);
+            rew = o.rew;
+            done = o.done;
+            failed = o.failed;
+            ret += o.rew;
+            if (o.err && valid) d.err[i] = 1;
+        } else {
+            rew = 0.f;
+        }
+        if (REC) {
+            store_record<E, REC>(d.traj_rec + (rec0 + (size_t)t) * Rec<E, REC>::F * ld, ld, i, ow, a, rew, s_pre, a_app, h_pre);
+            db.put(d, i, rec0 + (size_t)t, done, t == k_steps - 1);
+        }
+        bool fin = done && valid && !frozen;
+        if (AR) {
+            auto_reset<E, UNI>(T, d, fin, i, reset_seed, c, s, h, step, ret, yielded, es);
+            if (!UNI) E::act_bounds(c, alo, ahi);
+        } else {
+            if (fin) {
+                es.count += 1u;
+                es.retsum += ret;
+                es.lensum += step;
+            }
+            if (d.log_episodes) append_episode(d, fin, i, ret, step);
+            frozen |= done;
+        }
+        E::observe(s, ob);
+    }
+    if (!envw) return;
+#pragma unroll
+    for (int j = 0; j < E::S; ++j) d.state[j * ld + i] = s[j];
+#pragma unroll
+    for (int j = 0; j < E::H; ++j) d.hidden[j * ld + i] = h[j];
+#pragma unroll
+    for (int j = 0; j < E::O; ++j) d.obs[j * ld + i] = ob[j];
+    d.step[i] = step;
+    d.ret[i] = ret;
+    d.rew[i] = rew;
+    d.done[i] = done;
+    d.failed[i] = failed;
+    if (E::FINAL != FINAL_NONE) d.yielded[i] = yielded;
+    d.ep_idx[i] = es.epi;
+    d.es_count[i] = es.count;
+    d.es_retsum[i] = es.retsum;
+    d.es_lensum[i] = es.lensum;
+}
+
 // ------------------------------------------------------------------------------------ wave-specialised rollout kernel
 // At the size of the headline metric (65 536 envs) k_rollout has exactly one wave per SIMD, and a lone wave issues a VALU
 // instruction only every ~7 cycles while the SIMD takes one every 4 from two or more waves (the same
@@ -846,17 +1105,6 @@ __global__ __launch_bounds__(BLOCK) void k_rollout(Task T, Dev d, int k_steps, u
 // Not covered here (vs_step_random falls back to k_rollout): live domain randomisation for the families whose C wave reads
 // per-env constants (action bounds, c_max: they change at a reset inside the launch), the wrapper pipeline, the
 // state-and-time dependent final reward (needs s_{t+1} on the C side).
-enum : unsigned { WSF_DONE = 1u, WSF_FAILED = 2u, WSF_FROZEN = 4u, WSF_FIN = 8u };
-
-__device__ __forceinline__ void ws_barrier() {
-#ifdef VS_WS_NOSYNC  // diagnostic builds only (timing without the exchange; results are wrong)
-    return;
-#endif
-    // LDS traffic only: wait for this wave's LDS ops (lgkmcnt(0)), not for its global stores (a __syncthreads() would also
-    // drain vmcnt and stall the C wave on its record stores in every phase)
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
 // NE = envs per workgroup (a workgroup is NE / 64 P waves followed by NE / 64 C waves):
 //   256  512 threads; wave w and w + 4 share a SIMD, so every SIMD of the CU holds one P and one C wave -- the shape for
 //        one workgroup per compute unit (65 536 envs on 256 CUs)
@@ -1354,7 +1602,7 @@ __global__ __launch_bounds__(NR * NE, NR == 3 ? 3 : 1) void k_rollout_ws(Task T,
                     E::observe_c(v, v + TR0, ob);
                     const int t = bb * WS_R + r;
                     float* row = d.traj_rec + (rec0 + (size_t)t) * Rec<E, REC>::F * ld;
-                    reinterpret_cast<float4*>(row)[i] = make_float4(ob[0], ob[1], ob[2], ob[3]);
+                    Planes<4>::template store<0, true>(row, ld, i, ob);
                 }
             };
             auto obs_work = [&](int bb) __attribute__((always_inline)) {
@@ -1561,6 +1809,7 @@ struct vs_env {
     vs::DrSpecs* d_specs = nullptr;   // device scratch for vs_sample_params
     float* d_pbuf = nullptr;      // DomainRandWrapperBuffer parameter sets
     float* d_ring = nullptr;      // ActDelayWrapper ring (Pipe::ring)
+    vs::Fnn fnn{};                // vs_set_policy_fnn: the network vs_step_policy evaluates (fnn.w == nullptr: none)
     int rollout_variant = -1;     // vs_set_rollout_variant: -1 automatic, 0 k_rollout, 1 k_rollout_ws<256>, 2 k_rollout_ws<64>, 3 / 4 the three-role kernel in 64 / 256-env workgroups
     int n_cu = 256;               // compute units of the device (256 on MI355X)
     bool auto_reset = false;
@@ -1591,6 +1840,7 @@ template <class E>
 struct Launch {
     static void step(vs_env* h, const float* act, long es, long ds, int rec = 0, int row = 0);
     static void rollout(vs_env* h, int k, uint64_t seed, uint64_t ep, int rec);
+    static void rollout_fnn(vs_env* h, int k, int rec, uint64_t noise_seed);  // vs_step_policy
     static int variant(vs_env* h);  // RolloutVariant vs_step_random would launch for the handle's configuration
     static void jac(vs_env* h, const float* act, long es, long ds);
     static void set_params(vs_env* h, const float* src, long pitch, int bcast, const uint8_t* mask);
@@ -1618,7 +1868,7 @@ void launch_step_mixed(const Segs* dev_segs, int total_blocks, hipStream_t st, b
 //     not the cartpole's 224);
 //   * beyond: k_rollout has two or more waves per SIMD by itself;
 //   * the families with E::WS_G3 (QQube, oscillator, pendulum) run THREE waves per 64 envs up to 256 envs per compute unit
-//     (profiles/r03_table_variants.txt: QQube at 65 536 envs 44.8 -> 37.7 us, at 4 096 envs 32.7 -> 27.1 us per 100 steps).
+//     (profiles/r02_table_three_roles.txt: QQube at 65 536 envs 44.8 -> 37.7 us, at 4 096 envs 32.7 -> 27.1 us per 100 steps).
 // VS_ROLLOUT_VARIANT=plain|ws|ws64|g64|g256 overrides for every handle (experiments); vs_set_rollout_variant pins per handle.
 template <class E>
 int Launch<E>::variant(vs_env* h) {
@@ -1710,6 +1960,19 @@ void Launch<E>::rollout(vs_env* h, int k, uint64_t seed, uint64_t ep, int rec) {
     } else {
         if (ar) launch_plain<E, false, true, false>(h, k, seed, ep, rec); else launch_plain<E, false, false, false>(h, k, seed, ep, rec);
     }
+}
+
+template <class E>
+void Launch<E>::rollout_fnn(vs_env* h, int k, int rec, uint64_t noise_seed) {
+    const bool uni = h->uniform && h->dr.n == 0 && h->d.pbuf_n == 0;
+    constexpr int FW = 8;  // waves per 64 envs: 8 hidden units of a 64-wide layer each
+    dim3 g((unsigned)(h->d.ld / 64)), b(64 * FW);
+#define LF(U, AR, REC) hipLaunchKernelGGL((k_rollout_fnn<E, U, AR, REC, FW>), g, b, 0, h->stream, h->task, h->d, h->fnn, k, h->ar_seed, noise_seed)
+#define LFR(U, AR) { if (rec == 0) LF(U, AR, 0); else if (rec == 1) LF(U, AR, 1); else LF(U, AR, 2); }
+    if (uni) { if (h->auto_reset) LFR(true, true) else LFR(true, false) }
+    else { if (h->auto_reset) LFR(false, true) else LFR(false, false) }
+#undef LFR
+#undef LF
 }
 
 template <class E>
