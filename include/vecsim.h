@@ -134,6 +134,26 @@ typedef struct vs_dp_spec {
     int32_t roundint;    /* DomainParam(roundint=True): round half to even after clipping (domain_parameter.py:127-129) */
 } vs_dp_spec;
 
+/* A feed-forward network policy for vs_step_policy: FNN(input, output, hidden_sizes, hidden_nonlin, output_nonlin)
+ * of P/policies/feed_back/fnn.py:43-160 (dropout 0).  Hidden layers are at most 64 units wide. */
+#define VS_NL_NONE 0
+#define VS_NL_TANH 1
+#define VS_NL_RELU 2
+#define VS_NL_SIGMOID 3
+#define VS_FNN_MAX_HIDDEN 4
+#define VS_FNN_MAX_WIDTH 64
+typedef struct vs_fnn_desc {
+    int32_t n_hidden;          /* 1 .. VS_FNN_MAX_HIDDEN hidden layers */
+    int32_t hidden[4];         /* their sizes, 1 .. VS_FNN_MAX_WIDTH each */
+    int32_t hidden_nonlin[4];  /* VS_NL_* per hidden layer */
+    int32_t output_nonlin;     /* VS_NL_* of the output layer */
+    int32_t feat;              /* 0: the input is the visible observation; 1: the fork's FNNPolicy.forward featurisation
+                                  [o_0, sin o_1, cos o_1, o_2 ..] (fnn.py:219-222; one input more than observation rows) */
+    int32_t n_obs;             /* number of observation rows the policy sees; 0 = all of them, in order */
+    int32_t obs_idx[8];        /* ... and which (ObsPartialWrapper, P/environment_wrappers/observation_partial.py:36-75) */
+    float noise_std[2];        /* exploration: + std * N(0, 1) per action dimension (NormalActNoiseExplStrat); 0 = none */
+} vs_fnn_desc;
+
 typedef struct vs_env* vs_handle;
 
 /* ---- static information (no GPU needed) ---- */
@@ -252,6 +272,16 @@ int vs_step_jac(vs_handle h, const float* actions, int64_t env_stride, int64_t d
  * k_steps env steps in ONE launch with on-device uniform actions in act_space, state kept in registers.
  * record != 0 streams obs/act/rew/done of every step into the VS_TRAJ_* buffers (k_steps <= vs_traj_capacity). */
 int vs_step_random(vs_handle h, uint64_t seed, int k_steps, int record);
+/* rollout() with a feed-forward network policy evaluated INSIDE the fused kernel (rollout.py:185-258 with act = policy(obs),
+ * rollout.py:203-219): vs_set_policy_fnn hands over the network -- `params` is the policy's flat parameter vector in torch
+ * order (per layer: weight [out][in] row-major, then bias [out]; hidden layers first, output layer last =
+ * parameters_to_vector(FNN.parameters()), fnn.py:104-112), host or device memory, copied -- and vs_step_policy runs k_steps
+ * env steps per launch: observation -> network -> (+ exploration noise) -> SimPyEnv.step -> record, exactly as
+ * vs_step_random does with its uniform policy (same records, auto-reset and freeze semantics).  The noise stream is
+ * Philox(noise_seed; global env index, episode index, step).  desc == NULL removes the network.
+ * Not available with a wrapper pipeline on the handle or for the discrete-action family (VS_ERR_STATE / VS_ERR_ARG). */
+int vs_set_policy_fnn(vs_handle h, const vs_fnn_desc* desc, const float* params, int64_t n_params);
+int vs_step_policy(vs_handle h, int k_steps, int record, uint64_t noise_seed);
 /* The action stream of vs_step_random is Philox(seed; global env index, absolute step index); the handle counts the
  * steps it has taken.  vs_seek_random repositions that counter (0 = start of a fresh batch of rollouts). */
 int vs_seek_random(vs_handle h, uint64_t step_index);

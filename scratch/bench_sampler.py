@@ -1,26 +1,59 @@
-import sys, time, json
-sys.path.insert(0, '.')
-import numpy as np, torch
-import simurlacra_amd as vs
-from simurlacra_amd.policies import DummyPolicy, Policy
-from simurlacra_amd.sampling import ParallelRolloutSampler
+"""ParallelRolloutSampler.sample() end to end (rollouts as StepSequences on the host), and the raw rate of vs_step_policy.
+usage: python scratch/bench_sampler.py"""
+import json
+import os
+import sys
+import time
 
-class MLP(Policy):
-    def __init__(self, spec, hidden=64):
-        super().__init__(spec)
-        o, a = spec.obs_space.flat_dim, spec.act_space.flat_dim
-        self.net = torch.nn.Sequential(torch.nn.Linear(o, hidden), torch.nn.Tanh(), torch.nn.Linear(hidden, hidden), torch.nn.Tanh(), torch.nn.Linear(hidden, a))
-    def forward(self, obs):
-        return self.net(obs)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
-for name, kw, n in (("qq-su", dict(dt=0.004, max_steps=4000), 4096), ("bob", dict(dt=0.01, max_steps=500), 4096), ("omo", dict(dt=0.02, max_steps=300), 16384)):
+import simurlacra_amd as vs  # noqa: E402
+from simurlacra_amd.policies import DummyPolicy, FNNPolicy  # noqa: E402
+from simurlacra_amd.sampling import ParallelRolloutSampler  # noqa: E402
+
+torch.manual_seed(0)
+for name, kw, n in (("qq-su", dict(dt=0.004, max_steps=4000), 4096), ("bob", dict(dt=0.01, max_steps=500), 4096),
+                    ("omo", dict(dt=0.02, max_steps=300), 16384), ("qq-su", dict(dt=0.004, max_steps=4000), 65536)):
     env = vs.ENV_CLASSES[name](**kw)
-    for pol_name, pol in (("DummyPolicy (fused)", DummyPolicy(env.spec)), ("MLP 64x64 (policy in the loop)", MLP(env.spec))):
-        s = ParallelRolloutSampler(env, pol, 8, min_rollouts=n, seed=0)
+    fnn = FNNPolicy(env.spec, [64, 64], torch.tanh, featurize=False)
+    for pol_name, pol, fuse in (("DummyPolicy (fused)", DummyPolicy(env.spec), True),
+                                ("FNNPolicy 64x64 tanh, in the kernel (vs_step_policy)", fnn, True),
+                                ("FNNPolicy 64x64 tanh, torch in the loop (vs_step_record per step)", fnn, False)):
+        if n > 16384 and not fuse:
+            continue
+        s = ParallelRolloutSampler(env, pol, 8, min_rollouts=n, seed=0, fuse_policy=fuse)
         s.sample()  # warm-up (handle creation)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         ros = s.sample()
         el = time.perf_counter() - t0
         steps = sum(len(r) for r in ros)
-        print(json.dumps(dict(env=name, policy=pol_name, rollouts=len(ros), env_steps=steps, seconds=round(el, 3), env_steps_per_s=round(steps / el))))
+        print(json.dumps(dict(env=name, policy=pol_name, rollouts=len(ros), env_steps=steps, seconds=round(el, 3),
+                              env_steps_per_s=round(steps / el))), flush=True)
+
+# the kernel alone: k steps per launch, auto-reset, records on
+for name, n in (("qq-su", 4096), ("qq-su", 16384), ("qq-su", 65536), ("qq-su", 262144), ("qcp-su", 65536), ("qbb", 32768)):
+    from bench import ENV_KW
+
+    e = vs.VecSimEnv(name, n, **ENV_KW[name])
+    O, A = e.dims["O"], e.dims["A"]
+    net = vs.FNN(O, A, [64, 64], torch.tanh)
+    e.set_policy_fnn(net.param_values, [64, 64], "tanh", noise_std=np.full(A, 0.1, dtype=np.float32))
+    e.set_auto_reset(True, seed=1)
+    e.reset(seed=2)
+    for rec in (1, 0):
+        if rec:
+            e.set_traj_capacity(200)
+        for _ in range(2):
+            e.step_policy(200, record=bool(rec), noise_seed=3)
+        e.sync()
+        e.timer_start()
+        for _ in range(5):
+            e.step_policy(200, record=bool(rec), noise_seed=3)
+        ms = e.timer_stop() / 5
+        print(json.dumps(dict(kernel="k_rollout_fnn", env=name, envs=n, net="64x64 tanh + noise", record=rec, us_per_step=round(ms * 1e3 / 200, 3),
+                              env_steps_per_s=round(n * 200 / (ms * 1e-3)))), flush=True)
+    e.close()

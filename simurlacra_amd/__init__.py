@@ -32,7 +32,7 @@ def __getattr__(name):
         from . import sampling
 
         return getattr(sampling, name)
-    if name in ("DummyPolicy", "IdlePolicy", "Policy"):
+    if name in ("DummyPolicy", "IdlePolicy", "Policy", "FNN", "FNNPolicy", "NormalActNoiseExplStrat", "fnn_kernel_spec"):
         from . import policies
 
         return getattr(policies, name)

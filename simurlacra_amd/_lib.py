@@ -11,7 +11,9 @@ ENV_TYPES = {"omo": 0, "bob": 1, "qq-su": 2, "qcp-su": 3, "qbb": 4, "qq-st": 5, 
  VS_EP_RETURNS, VS_EP_LENGTHS, VS_EP_ENVIDX, VS_EP_COUNT, VS_TRAJ_REC, _VS_RESERVED_15, _VS_RESERVED_16, VS_TRAJ_DONE,
  VS_FAILED, VS_EPSTAT_COUNT, VS_EPSTAT_RETSUM, VS_EPSTAT_LENSUM, VS_JAC_STATE, VS_JAC_REW, VS_JAC_OBS) = range(25)
 VS_FLAG_SIMPLE_DYNAMICS, VS_FLAG_LONG_POLE, VS_FLAG_ACT_NORM, VS_FLAG_FREEZE_DONE = 1, 2, 4, 8
-RV_PLAIN, RV_WS256, RV_WS64 = 0, 1, 2  # vs_rollout_variant
+RV_PLAIN, RV_WS256, RV_WS64, RV_WS64G, RV_WS256G = 0, 1, 2, 3, 4  # vs_rollout_variant
+VS_NL_NONE, VS_NL_TANH, VS_NL_RELU, VS_NL_SIGMOID = 0, 1, 2, 3  # vs_fnn_desc nonlinearities
+VS_FNN_MAX_HIDDEN, VS_FNN_MAX_WIDTH = 4, 64
 VS_DP_NORMAL, VS_DP_UNIFORM, VS_DP_BERNOULLI = 0, 1, 2
 VS_MAX_ACT_DELAY = 64
 
@@ -25,6 +27,12 @@ class TaskCfg(C.Structure):
 class DpSpec(C.Structure):
     _fields_ = [("param_index", C.c_int32), ("kind", C.c_int32), ("mean", C.c_float), ("spread", C.c_float),
                 ("clip_lo", C.c_float), ("clip_up", C.c_float), ("aux", C.c_float), ("roundint", C.c_int32)]
+
+
+class FnnDesc(C.Structure):
+    _fields_ = [("n_hidden", C.c_int32), ("hidden", C.c_int32 * 4), ("hidden_nonlin", C.c_int32 * 4),
+                ("output_nonlin", C.c_int32), ("feat", C.c_int32), ("n_obs", C.c_int32), ("obs_idx", C.c_int32 * 8),
+                ("noise_std", C.c_float * 2)]
 
 
 _P = C.c_void_p
@@ -62,6 +70,8 @@ _SIGNATURES = {
     "vs_set_record_row": (C.c_int, [_P, C.c_int]),
     "vs_step_random": (C.c_int, [_P, C.c_uint64, C.c_int, C.c_int]),
     "vs_seek_random": (C.c_int, [_P, C.c_uint64]),
+    "vs_set_policy_fnn": (C.c_int, [_P, C.POINTER(FnnDesc), _P, C.c_int64]),
+    "vs_step_policy": (C.c_int, [_P, C.c_int, C.c_int, C.c_uint64]),
     "vs_rollout_variant": (C.c_int, [_P]),
     "vs_set_rollout_variant": (C.c_int, [_P, C.c_int]),
     "vs_set_traj_capacity": (C.c_int, [_P, C.c_int]),

@@ -404,6 +404,7 @@ int vs_destroy(vs_handle h) {
     if (h->stage_mask) (void)hipFree(h->stage_mask);
     if (h->d_pbuf) (void)hipFree(h->d_pbuf);
     if (h->d_ring) (void)hipFree(h->d_ring);
+    if (h->fnn.w) (void)hipFree((void*)h->fnn.w);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -767,6 +768,92 @@ int vs_step_random(vs_handle h, uint64_t seed, int k_steps, int record) {
     uint64_t ep = h->epoch;
     h->epoch += (uint64_t)k_steps;
     DISPATCH_ENV(h->type, Launch<E>::rollout(h, k_steps, seed, ep, record ? h->record_mode : 0));
+    HIPCHK(h, hipGetLastError());
+    return VS_OK;
+}
+
+int vs_set_policy_fnn(vs_handle h, const vs_fnn_desc* desc, const float* params, int64_t n_params) {
+    if (!h) return VS_ERR_ARG;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (h->fnn.w) { HIPCHK(h, hipFree((void*)h->fnn.w)); }
+    h->fnn = Fnn{};
+    if (!desc) return VS_OK;
+    const EnvInfo& ei = ENV_INFO[h->type];
+    if (h->type == VS_ENV_BOB_D) return fail(h, VS_ERR_ARG, "vs_set_policy_fnn: the discrete-action family takes no network policy");
+    if (!params || desc->n_hidden < 1 || desc->n_hidden > FNN_MAXH) return fail(h, VS_ERR_ARG, "vs_set_policy_fnn: 1 .. 4 hidden layers and a parameter vector");
+    Fnn f{};
+    f.n_hidden = desc->n_hidden;
+    f.n_vis = desc->n_obs > 0 ? desc->n_obs : ei.O;
+    if (f.n_vis > ei.O) return fail(h, VS_ERR_ARG, "vs_set_policy_fnn: more visible observation rows than the env has");
+    f.ident = 1;
+    for (int k = 0; k < f.n_vis; ++k) {
+        f.obs_idx[k] = desc->n_obs > 0 ? desc->obs_idx[k] : k;
+        if (f.obs_idx[k] < 0 || f.obs_idx[k] >= ei.O) return fail(h, VS_ERR_ARG, "vs_set_policy_fnn: obs_idx out of range");
+        if (f.obs_idx[k] != k) f.ident = 0;
+    }
+    if (f.n_vis != ei.O) f.ident = 0;
+    f.feat = desc->feat != 0;
+    if (f.feat && f.n_vis < 2) return fail(h, VS_ERR_ARG, "vs_set_policy_fnn: the sin / cos featurisation needs two observation rows");
+    f.in_dim = f.n_vis + f.feat;
+    f.out_dim = ei.A;
+    f.out_nonlin = desc->output_nonlin;
+    int64_t need = 0;
+    int off = 0, last = f.in_dim;
+    for (int l = 0; l < f.n_hidden; ++l) {
+        f.hidden[l] = desc->hidden[l];
+        f.hid_nonlin[l] = desc->hidden_nonlin[l];
+        if (f.hidden[l] < 1 || f.hidden[l] > FNN_W) return fail(h, VS_ERR_ARG, "vs_set_policy_fnn: hidden layers are 1 .. 64 units wide");
+        if (f.hid_nonlin[l] < 0 || f.hid_nonlin[l] > FNN_SIGMOID) return fail(h, VS_ERR_ARG, "vs_set_policy_fnn: unknown nonlinearity");
+        need += (int64_t)f.hidden[l] * last + f.hidden[l];
+        f.off_w[l] = off;
+        off += (l == 0 ? last : FNN_W) * FNN_W;  // layers behind the first read all 64 (zero-padded) input rows
+        f.off_b[l] = off;
+        off += FNN_W;
+        last = f.hidden[l];
+    }
+    if (f.out_nonlin < 0 || f.out_nonlin > FNN_SIGMOID) return fail(h, VS_ERR_ARG, "vs_set_policy_fnn: unknown nonlinearity");
+    need += (int64_t)ei.A * last + ei.A;
+    f.off_w[f.n_hidden] = off;
+    off += ei.A * FNN_W;
+    f.off_b[f.n_hidden] = off;
+    off += 8;
+    if (n_params != need) return fail(h, VS_ERR_ARG, "vs_set_policy_fnn: parameter count does not match the layer sizes");
+    for (int j = 0; j < ei.A; ++j) {
+        f.noise_std[j] = desc->noise_std[j];
+        if (!(f.noise_std[j] >= 0.f)) return fail(h, VS_ERR_ARG, "vs_set_policy_fnn: noise_std must be >= 0");
+        if (f.noise_std[j] > 0.f) f.noisy = 1;
+    }
+    // torch layout -> transposed, zero-padded rows: unit j of layer l reads Wt_l[k][j], contiguous over j (scalar-load friendly)
+    std::vector<float> src((size_t)need), pk((size_t)off, 0.f);
+    HIPCHK(h, hipMemcpy(src.data(), params, (size_t)need * sizeof(float), is_device_ptr(params) ? hipMemcpyDeviceToHost : hipMemcpyHostToHost));
+    size_t q = 0;
+    last = f.in_dim;
+    for (int l = 0; l < f.n_hidden; ++l) {
+        for (int j = 0; j < f.hidden[l]; ++j)
+            for (int k = 0; k < last; ++k) pk[(size_t)f.off_w[l] + (size_t)k * FNN_W + j] = src[q++];
+        for (int j = 0; j < f.hidden[l]; ++j) pk[(size_t)f.off_b[l] + j] = src[q++];
+        last = f.hidden[l];
+    }
+    for (int j = 0; j < ei.A; ++j)
+        for (int k = 0; k < last; ++k) pk[(size_t)f.off_w[f.n_hidden] + (size_t)j * FNN_W + k] = src[q++];
+    for (int j = 0; j < ei.A; ++j) pk[(size_t)f.off_b[f.n_hidden] + j] = src[q++];
+    float* dw = nullptr;
+    HIPCHK(h, hipMalloc((void**)&dw, pk.size() * sizeof(float)));
+    hipError_t e = hipMemcpy(dw, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(dw); return fail(h, VS_ERR_HIP, "vs_set_policy_fnn: upload", e); }
+    f.w = dw;
+    h->fnn = f;
+    return VS_OK;
+}
+
+int vs_step_policy(vs_handle h, int k_steps, int record, uint64_t noise_seed) {
+    if (!h || k_steps < 1) return fail(h, VS_ERR_ARG, "vs_step_policy: bad argument");
+    if (!h->fnn.w) return fail(h, VS_ERR_STATE, "vs_step_policy: no network set (vs_set_policy_fnn)");
+    if (h->d.pipe.act_on || h->d.pipe.obs_on) return fail(h, VS_ERR_STATE, "vs_step_policy: not available with a wrapper pipeline on the handle");
+    if (record && h->d.traj_t0 + k_steps > h->traj_cap) return fail(h, VS_ERR_STATE, "vs_step_policy: traj offset + k_steps exceeds vs_set_traj_capacity");
+    HIPCHK(h, hipSetDevice(h->device));
+    DISPATCH_ENV(h->type, Launch<E>::rollout_fnn(h, k_steps, record ? h->record_mode : 0, noise_seed));
     HIPCHK(h, hipGetLastError());
     return VS_OK;
 }

@@ -863,20 +863,29 @@ __device__ __forceinline__ void ws_barrier() {
 //   act = W_out f(... f(W_1 x + b_1) ...) + b_out  [output_nonlin]  [+ std * N(0, 1): NormalActNoiseExplStrat]
 //   x   = the observation rows the policy sees (ObsPartialWrapper: Fnn::obs_idx), optionally in the fork's featurisation
 //         [o_0, sin o_1, cos o_1, o_2 ..] (FNNPolicy.forward, fnn.py:219-222)
-// Shape of the work on CDNA4: one workgroup = 64 envs x FW waves.  The network of 64 envs is a [64 x in] x [in x 64] product
-// per layer with fp32 accuracy to keep (the policy's torch reference is fp32): every wave computes 64 / FW of a layer's 64
-// (zero-padded) units for all 64 envs -- lane = env, weights arrive as SCALAR loads (s_load_dwordx8: the row of a layer's
-// transposed, padded weight matrix is wave-uniform), activations are exchanged through LDS ([unit][lane]: conflict-free) with
-// one LDS-only barrier per layer.  Wave 0 additionally owns the envs: it writes the observation, evaluates the (narrow)
-// output layer, draws the exploration noise and runs the very step code of k_rollout (same records, same reset path).
-// fp32 FMAs on the vector ALU, not MFMA: the fp32 MFMA rate equals the vector rate on this chip and a 64-wide hidden layer
-// spread over 8 waves is 8 FMAs per input and wave; bf16 MFMA would change the policy's numerics.
-constexpr int FNN_MAXH = 4;  // hidden layers
-constexpr int FNN_W = 64;    // padded width of a hidden layer
+// Shape of the work on CDNA4: one workgroup = 64 envs x 8 (or 4, fnn_waves) waves, and TWO lane mappings.
+//   * The network runs "lane = hidden unit": lane j of every wave keeps unit j's weight rows of all layers in VGPRs for
+//     the whole launch (weights stationary: no weight traffic at all inside the step loop), and a wave evaluates the
+//     network for its share (8 or 16) of the workgroup's envs one after the other.  An env's activation vector is uniform over
+//     the lanes: it is read from LDS as broadcast ds_read_b128 (one address for the whole wave: no bank conflicts), four
+//     inputs per instruction, and a layer of 64 x 64 is 16 LDS reads + 64 FMAs per env.  The narrow output layer is a
+//     product per lane and a DPP wave reduction.
+//   * The envs run "lane = env" on wave 0, with the very step code of k_rollout (same records, same reset path); the
+//     two mappings meet in LDS twice per step: observations [env][input] in, actions [env][A] out, one LDS-only barrier each.
+// fp32 FMAs on the vector ALU, not MFMA: the fp32 MFMA rate equals the vector rate on this chip, and bf16 MFMA would change
+// the policy's numerics (its torch reference is fp32).  A first version with "lane = env" in the network too -- weights as
+// scalar loads, units split over the waves -- spent its time waiting for SMEM (7.3 us per step at <= 16 384 envs).
+constexpr int FNN_MAXH = 4;   // hidden layers
+constexpr int FNN_W = 64;     // padded width of a hidden layer = lanes of a wave
+constexpr int FNN_XS = 12;    // padded width of the input row (in_dim <= MAXO + 1 = 9): three 16-B reads
+// waves per 64 envs: 8 (two per SIMD, 256 VGPRs each) while one 64-wide hidden-to-hidden weight row set fits beside the env
+// state; 4 (one per SIMD, 512 VGPRs) for three and four hidden layers, whose 128 / 192 weight registers would spill
+__host__ __device__ constexpr int fnn_waves(int n_hidden) { return n_hidden <= 2 ? 8 : 4; }
 enum FnnNonlin { FNN_ID = 0, FNN_TANH = 1, FNN_RELU = 2, FNN_SIGMOID = 3 };
 struct Fnn {
-    const float* w;  // device, packed by vs_set_policy_fnn: per hidden layer l  Wt_l [in_l][64] (unit-contiguous rows, zero
-                     // padded) at off_w[l] and b_l [64] at off_b[l]; output layer  Wo [A][64] at off_w[n_hidden], bo [A]
+    const float* w;  // device, packed by vs_set_policy_fnn: per hidden layer l  Wt_l [in_l][64] (row k = input k, unit-
+                     // contiguous, zero padded) at off_w[l] and b_l [64] at off_b[l]; output layer  Wo [A][64] at
+                     // off_w[n_hidden], bo [A] at off_b[n_hidden]
     int n_hidden, in_dim, out_dim;
     int hidden[FNN_MAXH];
     int hid_nonlin[FNN_MAXH], out_nonlin;
@@ -903,22 +912,51 @@ __device__ __forceinline__ float fnn_nonlin(int kind, float x) {  // kind is wav
     return x;
 }
 
-typedef const __attribute__((address_space(4))) float* cfloat_p;  // constant address space: loads are scalar (SMEM)
+// sum over the 64 lanes of a wave, valid in lane 63: DPP only (quad swaps, row mirrors, row broadcasts) -- nothing through
+// the LDS crossbar
+__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+#define VS_DPP_ADD(ctrl, rmask)                                                                                             \
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rmask, 0xF, false))
+    VS_DPP_ADD(0xB1, 0xF);   // quad_perm [1, 0, 3, 2]
+    VS_DPP_ADD(0x4E, 0xF);   // quad_perm [2, 3, 0, 1]
+    VS_DPP_ADD(0x141, 0xF);  // row_half_mirror
+    VS_DPP_ADD(0x140, 0xF);  // row_mirror: every lane of a row of 16 holds the row's sum
+    VS_DPP_ADD(0x142, 0xA);  // row_bcast15 into rows 1 and 3
+    VS_DPP_ADD(0x143, 0xC);  // row_bcast31 into rows 2 and 3
+#undef VS_DPP_ADD
+    return v;
+}
 
-template <class E, bool UNI, bool AR, int REC, int FW>
-__global__ __launch_bounds__(64 * FW) void k_rollout_fnn(Task T, Dev d, Fnn P, int k_steps, uint64_t reset_seed,
-                                                         uint64_t noise_seed) {
-    static_assert(FW == 1 || FW == 2 || FW == 4 || FW == 8, "waves per 64 envs");
-    constexpr int NJ = FNN_W / FW;  // hidden units per wave
-    __shared__ float l_x[2][FNN_W * 64];  // activations [unit][lane], ping-pong between layers
+template <class E, bool AR, int REC, int NHID>
+__global__ __launch_bounds__(64 * fnn_waves(NHID)) void k_rollout_fnn(Task T, Dev d, Fnn P, int k_steps, uint64_t reset_seed,
+                                                                uint64_t noise_seed) {
+    static_assert(NHID >= 1 && NHID <= FNN_MAXH, "hidden layers");
+    constexpr bool UNI = false;          // per-env constants: Dev::consts is always kept (k_set_params), read once per launch
+    constexpr int EPW = 64 / fnn_waves(NHID);  // envs a wave evaluates the network for
+    __shared__ __attribute__((aligned(16))) float l_x[64 * FNN_XS];  // what the policy sees: [env][input]
+    __shared__ __attribute__((aligned(16))) float l_h[64 * FNN_W];   // activations of the running layer: [env][unit]
+    __shared__ float l_a[64 * MAXA];                                 // the network's output: [env][A]
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 64 + lane;
-    const bool envw = wave == 0;  // the wave that owns the 64 envs
+    const int i = blockIdx.x * 64 + lane;  // (wave 0: the env of this lane)
+    const bool envw = wave == 0;
     const size_t ld = d.ld;
     const size_t rec0 = (size_t)d.traj_t0;
     const bool valid = i < d.n;
-    const cfloat_p W = (cfloat_p)(uintptr_t)P.w;
+
+    // ---- unit `lane` of every layer: its weight rows, for the whole launch
+    float w1[FNN_XS], wh[NHID > 1 ? NHID - 1 : 1][FNN_W], bh[NHID], wo[E::A];
+#pragma unroll
+    for (int k = 0; k < FNN_XS; ++k) w1[k] = k < P.in_dim ? P.w[P.off_w[0] + k * FNN_W + lane] : 0.f;
+#pragma unroll
+    for (int l = 1; l < NHID; ++l) {
+#pragma unroll
+        for (int k = 0; k < FNN_W; ++k) wh[l - 1][k] = P.w[P.off_w[l] + k * FNN_W + lane];
+    }
+#pragma unroll
+    for (int l = 0; l < NHID; ++l) bh[l] = P.w[P.off_b[l] + lane];
+#pragma unroll
+    for (int j = 0; j < E::A; ++j) wo[j] = P.w[P.off_w[NHID] + j * FNN_W + lane];
 
     // ---- env state of the lane: wave 0 only (the other waves never touch it)
     float c[E::K], s[E::S], h[E::H > 0 ? E::H : 1], a[E::A], ob[E::O];
@@ -945,13 +983,13 @@ __global__ __launch_bounds__(64 * FW) void k_rollout_fnn(Task T, Dev d, Fnn P, i
         E::act_bounds(c, alo, ahi);
         E::observe(s, ob);
         if (REC) db.begin(d, i, rec0);
-        __builtin_amdgcn_s_waitcnt(0x0F70);  // (see rollout_body: nothing pending at the loop header)
     }
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // (see rollout_body: nothing pending at the loop header)
 
     for (int t = 0; t < k_steps; ++t) {
-        // ---- input layer: what the policy sees of obs_t
+        // ---- what the policy sees of obs_t: wave 0 writes its env's input row
         if (envw) {
-            float x[MAXO + 1];
+            float x[FNN_XS];
             if (P.ident) {
 #pragma unroll
                 for (int k = 0; k < MAXO; ++k) x[k] = k < E::O ? ob[k] : 0.f;
@@ -964,67 +1002,114 @@ __global__ __launch_bounds__(64 * FW) void k_rollout_fnn(Task T, Dev d, Fnn P, i
                     x[k] = v;
                 }
             }
+#pragma unroll
+            for (int k = MAXO; k < FNN_XS; ++k) x[k] = 0.f;
             if (P.feat) {  // [o_0, sin o_1, cos o_1, o_2 ..]
                 float sn, cs;
                 sincos_fast(x[1], &sn, &cs);
 #pragma unroll
                 for (int k = MAXO; k >= 3; --k) x[k] = x[k - 1];
                 x[1] = sn, x[2] = cs;
-            } else {
-                x[MAXO] = 0.f;
             }
-#pragma unroll
-            for (int k = 0; k <= MAXO; ++k)
-                if (k < P.in_dim) l_x[0][k * 64 + lane] = x[k];
+            Planes<FNN_XS>::store(l_x, 1, lane * (FNN_XS / 4), x);  // three 16-B stores: row `lane`
         }
         ws_barrier();
-        // ---- hidden layers: every wave, NJ units each
-        int n_in = P.in_dim, cur = 0;
-        for (int l = 0; l < P.n_hidden; ++l) {
-            const cfloat_p wl = W + P.off_w[l] + wave * NJ;
-            const cfloat_p bl = W + P.off_b[l] + wave * NJ;
-            float acc[NJ];
+        // ---- the network for this wave's envs: lane = unit.  Layer by layer over the wave's EPW envs, in groups of QU envs
+        // whose code is one straight-line block (all of them for one and two hidden layers; two at a time, in a rolled loop,
+        // for deeper networks: code size).  Every LDS read below is one address for the whole wave (the env index is
+        // wave-uniform).  The nonlinearity kind is wave-uniform too: its switch sits outside the group.
+        constexpr int QU = NHID <= 2 ? EPW : 2;
+        auto with_kind = [&](int kind, auto&& body) __attribute__((always_inline)) {
+            if (kind == FNN_TANH) body(std::integral_constant<int, FNN_TANH>{});
+            else if (kind == FNN_RELU) body(std::integral_constant<int, FNN_RELU>{});
+            else if (kind == FNN_SIGMOID) body(std::integral_constant<int, FNN_SIGMOID>{});
+            else body(std::integral_constant<int, FNN_ID>{});
+        };
+        // what becomes of unit `lane`'s activation of env e: the next layer's input row (in place: the row has been read
+        // completely by then), or -- behind the last hidden layer -- the output layer: a product per unit and a wave reduction
+        // (padding units carry zero weights)
+        auto emit = [&](auto last, int e, float hv) __attribute__((always_inline)) {
+            if constexpr (decltype(last)::value) {
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) acc[j] = bl[j];
-            const float* xin = l_x[cur];
-#pragma unroll 4
-            for (int k = 0; k < n_in; ++k) {
-                const float xk = xin[k * 64 + lane];
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) acc[j] = fmaf(wl[k * FNN_W + j], xk, acc[j]);
+                for (int j = 0; j < E::A; ++j) {
+                    const float sum = wave_sum_to_lane63(wo[j] * hv);
+                    if (lane == 63) l_a[e * MAXA + j] = sum;
+                }
+            } else {
+                l_h[e * FNN_W + lane] = hv;
             }
-            float* xout = l_x[cur ^ 1];
-            const int nl = P.hid_nonlin[l];
+        };
+        with_kind(P.hid_nonlin[0], [&](auto kind) __attribute__((always_inline)) {
+#pragma unroll 1
+            for (int g = 0; g < EPW / QU; ++g) {
+                const int e0 = wave * EPW + g * QU;
+                float x[3][FNN_XS];  // input rows two envs ahead of the arithmetic
+                Planes<FNN_XS>::load(l_x, 1, e0 * (FNN_XS / 4), x[0]);
+                Planes<FNN_XS>::load(l_x, 1, (e0 + 1) * (FNN_XS / 4), x[1]);
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) xout[(wave * NJ + j) * 64 + lane] = fnn_nonlin(nl, acc[j]);
-            ws_barrier();
-            cur ^= 1;
-            n_in = P.hidden[l];
-        }
+                for (int q = 0; q < QU; ++q) {
+                    if (q + 2 < QU) Planes<FNN_XS>::load(l_x, 1, (e0 + q + 2) * (FNN_XS / 4), x[(q + 2) % 3]);
+                    float acc = bh[0];
+#pragma unroll
+                    for (int k = 0; k < FNN_XS; ++k) acc = fmaf(w1[k], x[q % 3][k], acc);
+                    emit(std::integral_constant<bool, NHID == 1>{}, e0 + q, fnn_nonlin(decltype(kind)::value, acc));
+                }
+            }
+        });
+        auto hidden_layer = [&](auto lc) __attribute__((always_inline)) {
+            constexpr int l = decltype(lc)::value;
+            with_kind(P.hid_nonlin[l], [&](auto kind) __attribute__((always_inline)) {
+                // a row of 64 inputs is four quarters of four 16-B reads; the reads of quarter n + 2 are issued before the 16
+                // FMAs of quarter n (a ring of three register buffers), across the envs of a group: the LDS latency hides
+                // behind the arithmetic
+#pragma unroll 1
+                for (int g = 0; g < EPW / QU; ++g) {
+                    const int e0 = wave * EPW + g * QU;
+                    constexpr int NQ4 = 4 * QU;
+                    float4 buf[3][4];
+                    auto issue = [&](int n, float4* dst) __attribute__((always_inline)) {
+                        const float4* row = reinterpret_cast<const float4*>(l_h + (e0 + n / 4) * FNN_W) + (n & 3) * 4;
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) dst[kk] = row[kk];
+                    };
+                    issue(0, buf[0]);
+                    issue(1, buf[1]);
+                    float acc = bh[l];
+#pragma unroll
+                    for (int n = 0; n < NQ4; ++n) {
+                        if (n + 2 < NQ4) issue(n + 2, buf[(n + 2) % 3]);
+                        const float4* x4 = buf[n % 3];
+                        const int k0 = (n & 3) * 16;
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) {
+                            acc = fmaf(wh[l - 1][k0 + 4 * kk], x4[kk].x, acc);
+                            acc = fmaf(wh[l - 1][k0 + 4 * kk + 1], x4[kk].y, acc);
+                            acc = fmaf(wh[l - 1][k0 + 4 * kk + 2], x4[kk].z, acc);
+                            acc = fmaf(wh[l - 1][k0 + 4 * kk + 3], x4[kk].w, acc);
+                        }
+                        if ((n & 3) == 3) {
+                            emit(std::integral_constant<bool, l == NHID - 1>{}, e0 + n / 4, fnn_nonlin(decltype(kind)::value, acc));
+                            acc = bh[l];
+                        }
+                    }
+                }
+            });
+        };
+        if constexpr (NHID > 1) hidden_layer(std::integral_constant<int, 1>{});
+        if constexpr (NHID > 2) hidden_layer(std::integral_constant<int, 2>{});
+        if constexpr (NHID > 3) hidden_layer(std::integral_constant<int, 3>{});
+        ws_barrier();
         if (!envw) continue;
-        // ---- output layer + exploration noise: the policy's action
-        {
-            const cfloat_p wo = W + P.off_w[P.n_hidden];
-            const cfloat_p bo = W + P.off_b[P.n_hidden];
-            const float* xin = l_x[cur];
+        // ---- the policy's action of this lane's env (+ exploration noise)
 #pragma unroll
-            for (int j = 0; j < E::A; ++j) a[j] = bo[j];
-#pragma unroll 4
-            for (int k = 0; k < n_in; ++k) {
-                const float xk = xin[k * 64 + lane];
+        for (int j = 0; j < E::A; ++j) a[j] = fnn_nonlin(P.out_nonlin, l_a[lane * MAXA + j] + P.w[P.off_b[NHID] + j]);
+        if (P.noisy) {
+            // NormalActNoiseExplStrat: + std * N(0, 1), keyed like the wrapper noise by (env, episode, step)
+            uint4 b = Rng::philox(noise_seed, d.idx0 + (uint32_t)i, RNG_POLICY_NOISE, ((uint64_t)es.epi << 32) | (uint32_t)step);
+            float z[2];
+            Rng::box_muller(b.x, b.y, z[0], z[1]);
 #pragma unroll
-                for (int j = 0; j < E::A; ++j) a[j] = fmaf(wo[j * FNN_W + k], xk, a[j]);
-            }
-#pragma unroll
-            for (int j = 0; j < E::A; ++j) a[j] = fnn_nonlin(P.out_nonlin, a[j]);
-            if (P.noisy) {
-                // NormalActNoiseExplStrat: + std * N(0, 1), keyed like the wrapper noise by (env, episode, step)
-                uint4 b = Rng::philox(noise_seed, d.idx0 + (uint32_t)i, RNG_POLICY_NOISE, ((uint64_t)es.epi << 32) | (uint32_t)step);
-                float z[2];
-                Rng::box_muller(b.x, b.y, z[0], z[1]);
-#pragma unroll
-                for (int j = 0; j < E::A; ++j) a[j] = fmaf(P.noise_std[j], z[j], a[j]);
-            }
+            for (int j = 0; j < E::A; ++j) a[j] = fmaf(P.noise_std[j], z[j], a[j]);
         }
         // ---- the env step: rollout_body's, statement for statement
         float s_pre[E::S], h_pre[E::H > 0 ? E::H : 1], a_app[E::A], ow[E::O];
@@ -1055,7 +1140,7 @@ __global__ __launch_bounds__(64 * FW) void k_rollout_fnn(Task T, Dev d, Fnn P, i
         bool fin = done && valid && !frozen;
         if (AR) {
             auto_reset<E, UNI>(T, d, fin, i, reset_seed, c, s, h, step, ret, yielded, es);
-            if (!UNI) E::act_bounds(c, alo, ahi);
+            E::act_bounds(c, alo, ahi);
         } else {
             if (fin) {
                 es.count += 1u;
@@ -1964,13 +2049,17 @@ void Launch<E>::rollout(vs_env* h, int k, uint64_t seed, uint64_t ep, int rec) {
 
 template <class E>
 void Launch<E>::rollout_fnn(vs_env* h, int k, int rec, uint64_t noise_seed) {
-    const bool uni = h->uniform && h->dr.n == 0 && h->d.pbuf_n == 0;
-    constexpr int FW = 8;  // waves per 64 envs: 8 hidden units of a 64-wide layer each
-    dim3 g((unsigned)(h->d.ld / 64)), b(64 * FW);
-#define LF(U, AR, REC) hipLaunchKernelGGL((k_rollout_fnn<E, U, AR, REC, FW>), g, b, 0, h->stream, h->task, h->d, h->fnn, k, h->ar_seed, noise_seed)
-#define LFR(U, AR) { if (rec == 0) LF(U, AR, 0); else if (rec == 1) LF(U, AR, 1); else LF(U, AR, 2); }
-    if (uni) { if (h->auto_reset) LFR(true, true) else LFR(true, false) }
-    else { if (h->auto_reset) LFR(false, true) else LFR(false, false) }
+    dim3 g((unsigned)(h->d.ld / 64));
+#define LF(AR, REC, NH) hipLaunchKernelGGL((k_rollout_fnn<E, AR, REC, NH>), g, dim3(64 * fnn_waves(NH)), 0, h->stream, h->task, h->d, h->fnn, k, h->ar_seed, noise_seed)
+#define LFR(AR, NH) { if (rec == 0) LF(AR, 0, NH); else if (rec == 1) LF(AR, 1, NH); else LF(AR, 2, NH); }
+#define LFA(NH) { if (h->auto_reset) LFR(true, NH) else LFR(false, NH) }
+    switch (h->fnn.n_hidden) {
+        case 1: LFA(1) break;
+        case 2: LFA(2) break;
+        case 3: LFA(3) break;
+        default: LFA(4) break;
+    }
+#undef LFA
 #undef LFR
 #undef LF
 }

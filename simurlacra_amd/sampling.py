@@ -23,7 +23,7 @@ import numpy as np
 
 from . import _lib as L
 from .exceptions import TypeErr, ValueErr
-from .policies import DummyPolicy
+from .policies import DummyPolicy, fnn_kernel_spec
 from .seeding import derive_seed, get_base_seed, set_seed
 from .wrappers import DomainRandWrapperBuffer, DomainRandWrapperLive, fuse_wrappers, inner_env, typed_env
 
@@ -192,7 +192,7 @@ class ParallelRolloutSampler:
 
     def __init__(self, env, policy, num_workers: int = 1, *, min_rollouts: int = None, min_steps: int = None,
                  show_progress_bar: bool = False, seed=NO_SEED, batch_lanes: int = 65536, chunk: int = 128,
-                 full_records: bool = True):
+                 full_records: bool = True, fuse_policy: bool = True):
         if min_rollouts is None and min_steps is None:
             raise ValueErr(msg="At least one of min_rollouts and min_steps must be given")  # SamplerBase
         self.min_rollouts, self.min_steps = min_rollouts, min_steps
@@ -208,6 +208,9 @@ class ParallelRolloutSampler:
         # full_records: rollouts carry states / actions_applied / th_ddot like the reference's (rollout.py:305-325), at 13
         # instead of 8 floats per QQube step on the device; False keeps observations / actions / rewards only
         self._full = bool(full_records)
+        # fuse_policy: evaluate FNN / FNNPolicy networks (optionally inside a NormalActNoiseExplStrat) in the rollout kernel
+        # itself; False keeps every policy but DummyPolicy in torch (one recording step launch per env step)
+        self._fuse_policy = bool(fuse_policy)
         self._vecs = {}
 
     def _drop_handles(self):
@@ -347,6 +350,14 @@ class ParallelRolloutSampler:
         H = v.dims["H"]
         hid_t = v.tensor(L.VS_HIDDEN)[:, :n] if H else None
         use_fused = isinstance(self.policy, DummyPolicy)
+        # a feed-forward network policy the kernel can evaluate itself (vs_step_policy): rollout() with act = policy(obs)
+        # fused like the DummyPolicy path -- unless a wrapper pipeline (noise / delay / observation normalisation) is on
+        fc = self._fc
+        plain_chain = (fc.delay == 0 and not np.any(fc.noise_std) and not np.any(fc.noise_mean) and not np.any(fc.var)
+                       and np.all(fc.scale == 1) and not np.any(fc.shift))
+        fnn = fnn_kernel_spec(self.policy) if (self._fuse_policy and plain_chain and not use_fused) else None
+        if fnn is not None and base.name == "bob-d":
+            fnn = None
         state0 = st_t.t().clone()
         T_cap = int(max_steps)
         t = 0
@@ -377,6 +388,38 @@ class ParallelRolloutSampler:
                 return visible(obs_full, 0).t()
 
             def final_state(length, T):  # ... and VS_STATE / VS_HIDDEN the state it belongs to
+                return st_t.t(), (hid_t.t() if H else None)
+        elif fnn is not None:
+            # rollout() with a network policy == vs_step_policy: observation -> network -> (exploration noise) -> step ->
+            # record inside ONE kernel, `chunk` steps per launch, lanes freeze at done; the same record planes as above
+            if hasattr(self.policy, "reset"):
+                self.policy.reset()
+            if eval:
+                fnn = dict(fnn, noise_std=None)  # (the reference evaluates without exploration)
+            v.set_policy_fnn(obs_idx=None if fc.keep.all() else np.flatnonzero(fc.keep), **fnn)
+            v.set_record_mode(2 if full else 1)
+            v.set_traj_capacity(T_cap)
+            while t < T_cap:
+                k = int(min(self._chunk, T_cap - t))
+                v.set_traj_offset(t)
+                v.step_policy(k, record=True, noise_seed=lane_key ^ 0x8CB92BA72F3D8DD7)
+                t += k
+                if bool(done_t.bool().all()):  # one scalar sync per launch
+                    break
+            v.set_traj_offset(0)
+            fields = v.record_fields()
+            done_T = v.traj_done(t, n)  # [T, n]
+
+            def gather(ti, li):
+                rec = v.gather_traj(ti, li)
+                col = lambda k: rec[:, fields[k][0]:fields[k][0] + fields[k][1]]
+                extra = (col("state"), col("act_app"), col("hidden")) if full else None
+                return visible(col("obs"), 1), col("act"), rec[:, fields["rew"][0]], extra
+
+            def final_obs(length, T):
+                return visible(obs_full, 0).t()
+
+            def final_state(length, T):
                 return st_t.t(), (hid_t.t() if H else None)
         else:
             # policy in the loop: rollout() with the caller's policy (rollout.py:185-258).  One recording step kernel per env

@@ -490,6 +490,52 @@ class VecSimEnv:
         self._check(self._lib.vs_step_random(self._h, int(seed) & (2 ** 64 - 1), int(k_steps), int(bool(record))),
                     "vs_step_random")
 
+    # ------------------------------------------------------------------------------------------------ policy in the kernel
+    _NONLIN = {None: L.VS_NL_NONE, "none": L.VS_NL_NONE, "tanh": L.VS_NL_TANH, "relu": L.VS_NL_RELU, "sigmoid": L.VS_NL_SIGMOID}
+
+    def set_policy_fnn(self, params, hidden_sizes, hidden_nonlin="tanh", output_nonlin=None, feat=False, obs_idx=None,
+                       noise_std=None):
+        """Hand a feed-forward network policy (FNN of P/policies/feed_back/fnn.py:43-160) to the fused kernel of step_policy.
+        params: the flat parameter vector in torch order (parameters_to_vector(net.parameters())), a torch tensor or array;
+        hidden_nonlin: one name or one per hidden layer ('tanh' | 'relu' | 'sigmoid' | None); feat: the fork's FNNPolicy
+        featurisation [o_0, sin o_1, cos o_1, o_2 ..]; obs_idx: the observation rows the policy sees (ObsPartialWrapper);
+        noise_std: exploration noise per action dimension.  params=None removes the network."""
+        if params is None:
+            self._check(self._lib.vs_set_policy_fnn(self._h, None, None, 0), "vs_set_policy_fnn")
+            return
+        hs = [int(x) for x in hidden_sizes]
+        if not 1 <= len(hs) <= L.VS_FNN_MAX_HIDDEN or max(hs) > L.VS_FNN_MAX_WIDTH:
+            raise ValueErr(msg=f"the in-kernel policy takes 1..{L.VS_FNN_MAX_HIDDEN} hidden layers of at most "
+                               f"{L.VS_FNN_MAX_WIDTH} units, got {hs}")
+        nl = list(hidden_nonlin) if isinstance(hidden_nonlin, (list, tuple)) else [hidden_nonlin] * len(hs)
+        d = L.FnnDesc()
+        d.n_hidden = len(hs)
+        for k, (w, f) in enumerate(zip(hs, nl)):
+            d.hidden[k] = w
+            d.hidden_nonlin[k] = self._NONLIN[f]
+        d.output_nonlin = self._NONLIN[output_nonlin]
+        d.feat = int(bool(feat))
+        if obs_idx is not None:
+            idx = [int(x) for x in obs_idx]
+            d.n_obs = len(idx)
+            for k, x in enumerate(idx):
+                d.obs_idx[k] = x
+        if noise_std is not None:
+            for k, x in enumerate(np.atleast_1d(np.asarray(noise_std, dtype=np.float32))):
+                d.noise_std[k] = float(x)
+        if hasattr(params, "detach"):
+            params = params.detach().to("cpu").numpy()
+        flat = np.ascontiguousarray(np.asarray(params, dtype=np.float32).reshape(-1))
+        self._check(self._lib.vs_set_policy_fnn(self._h, C.byref(d), flat.ctypes.data_as(C.c_void_p), flat.size),
+                    "vs_set_policy_fnn")
+
+    def step_policy(self, k_steps=1, record=False, noise_seed=0):
+        """k_steps env steps in one launch with the network of set_policy_fnn in the loop (rollout() with act = policy(obs))"""
+        if record and getattr(self, "_traj_t0", 0) + k_steps > self._traj_cap:
+            self.set_traj_capacity(getattr(self, "_traj_t0", 0) + int(k_steps))
+        self._check(self._lib.vs_step_policy(self._h, int(k_steps), int(bool(record)), int(noise_seed) & (2 ** 64 - 1)),
+                    "vs_step_policy")
+
     def sync(self):
         self._check(self._lib.vs_sync(self._h), "vs_sync")
 

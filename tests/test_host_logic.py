@@ -436,3 +436,36 @@ def test_mixed_env_exposes_only_what_the_c_api_has():
     assert mixed_api == {"vs_mixed_create", "vs_mixed_destroy", "vs_mixed_last_error", "vs_mixed_step_random", "vs_mixed_step",
                          "vs_mixed_time_random"}
     assert not hasattr(MixedVecSimEnv, "step_jac") and not hasattr(MixedVecSimEnv, "dims")
+
+
+def test_fnn_policy_mirror_and_kernel_spec():
+    """FNN / FNNPolicy of P/policies/feed_back/fnn.py on the host: layer and parameter order, the fork's featurisation, and
+    what fnn_kernel_spec hands to the fused kernel (or refuses)"""
+    torch = pytest.importorskip("torch")
+    from simurlacra_amd.policies import FNN, FNNPolicy, NormalActNoiseExplStrat, fnn_kernel_spec
+    from simurlacra_amd.spaces import BoxSpace, EnvSpec
+
+    net = FNN(6, 1, [32, 16], torch.tanh)
+    names = [k for k, _ in net.named_parameters()]
+    assert names == ["hidden_layers.0.weight", "hidden_layers.0.bias", "hidden_layers.1.weight", "hidden_layers.1.bias",
+                     "output_layer.weight", "output_layer.bias"]
+    assert net.param_values.numel() == 6 * 32 + 32 + 32 * 16 + 16 + 16 + 1
+    x = torch.randn(5, 6)
+    want = net.output_layer(torch.tanh(net.hidden_layers[1](torch.tanh(net.hidden_layers[0](x)))))
+    assert torch.equal(net(x), want)
+    spec = EnvSpec(BoxSpace(-np.ones(5), np.ones(5)), BoxSpace(-np.ones(1), np.ones(1)), BoxSpace(-np.ones(4), np.ones(4)))
+    pol = FNNPolicy(spec, [64, 64], torch.tanh)  # the fork: one input more than observation rows
+    assert pol.net.hidden_layers[0].in_features == 6
+    obs = torch.randn(3, 5)
+    feat = torch.cat([obs[:, :1], torch.sin(obs[:, 1:2]), torch.cos(obs[:, 1:2]), obs[:, 2:]], dim=1)
+    assert torch.equal(pol(obs), pol.net(feat)) and pol(obs[0]).shape == (1,)
+    plain = FNNPolicy(spec, [8], torch.relu, featurize=False, output_nonlin=torch.tanh)
+    assert plain.net.hidden_layers[0].in_features == 5 and torch.equal(plain(obs), plain.net(obs))
+    ks = fnn_kernel_spec(pol)
+    assert ks["hidden_sizes"] == [64, 64] and ks["hidden_nonlin"] == ["tanh", "tanh"] and ks["feat"] and ks["noise_std"] is None
+    assert torch.equal(ks["params"], pol.param_values.detach())
+    ks = fnn_kernel_spec(NormalActNoiseExplStrat(plain, std_init=0.2))
+    assert ks["output_nonlin"] == "tanh" and ks["hidden_nonlin"] == ["relu"] and np.allclose(ks["noise_std"], 0.2)
+    for bad in (FNN(5, 1, [128], torch.tanh), FNN(5, 1, [8] * 5, torch.tanh), FNN(5, 1, [8], torch.nn.functional.elu),
+                FNN(5, 1, [8], torch.tanh, dropout=0.1), torch.nn.Linear(5, 1)):
+        assert fnn_kernel_spec(bad) is None  # too wide / too deep / unknown nonlinearity / dropout / not an FNN
