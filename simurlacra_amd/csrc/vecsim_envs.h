@@ -10,6 +10,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "vecsim_dual.h"
 
 namespace vs {
@@ -115,6 +117,18 @@ __device__ __forceinline__ void sincos_fast(float x, float* sn, float* cs) {
 __device__ __forceinline__ float rcp_fast(float x) {
     float r = __builtin_amdgcn_rcpf(x);
     return fmaf(fmaf(-x, r, 1.0f), r, r);
+}
+
+// sin and cos of a0 + dl from (sin a0, cos a0) by the addition theorems, for a SMALL increment dl (|dl| <~ 0.5: the stage
+// angles of an RK step are the step's angle plus dt/2 or dt times a rate).  Truncation error of the two series below
+// |dl|^9 / 9! and |dl|^8 / 8! (< 1e-8 at 0.5); 12 instructions against the 28 of a fresh range reduction + polynomials.
+template <class R>
+__device__ __forceinline__ void sincos_rot(const R& s0, const R& c0, const R& dl, R* sn, R* cs) {
+    R d2 = dl * dl;
+    R sd = dl + dl * d2 * (-1.6666667163e-1f + d2 * (8.3333337680e-3f + d2 * -1.9841270114e-4f));
+    R cd = 1.0f + d2 * (-0.5f + d2 * (4.1666667908e-2f + d2 * -1.3888889225e-3f));
+    *sn = s0 * cd + c0 * sd;
+    *cs = c0 * cd - s0 * sd;
 }
 
 template <int N>
@@ -234,6 +248,8 @@ struct EnvDefaults {
     // oscillator / pendulum -10 .. -20 %; ball-on-beam, cartpole and ball balancer, whose physics wave is the long one by
     // itself, gain nothing and keep two waves)
     static constexpr bool WS_G3 = false;
+    // ... and how many waves per SIMD its two-role kernel must leave room for (the register budget the compiler gets: 512 / n)
+    static constexpr int WS_MIN_WAVES = 1;
     // Env.limit_act -> BoxSpace.project_to (P/spaces/box.py:180-184); np.clip propagates NaN (fminf/fmaxf would drop it)
     template <class R>
     __device__ static void limit_act(const float*, const float* lo, const float* hi, const R* a_raw, R* a) {
@@ -504,6 +520,7 @@ struct QcpT : EnvDefaults<1> {
     static constexpr int WS_SHAPE_FULL = 256;
     static constexpr bool WS_MID = false;
     static constexpr int WS_PREP_C = 1;  // a chain of four dependent _dynamics evaluations: every instruction off it counts
+    static constexpr int WS_MIN_WAVES = 2;  // 65 536 envs in 64-env workgroups are two waves per SIMD: at most 256 VGPRs
     static constexpr bool SYMMETRIC_BOX = V == 0;
     static constexpr int FINAL = V == 1 ? FINAL_STATE_TIME : FINAL_NONE;
     enum { C_KA, C_ETA_M, C_KB, C_MTG, C_MPL2, C_MU, C_M00, C_MPL, C_M11, C_BEQ, C_BP, C_MPLG, C_TH_NEG, C_TH_POS,
@@ -544,7 +561,7 @@ struct QcpT : EnvDefaults<1> {
     __device__ static void act_bounds(const float*, float* lo, float* hi) { hi[0] = 6.0f; lo[0] = -6.0f; }  // MAX_ACT_QCP
     // one evaluation of QCartPoleSim._dynamics (:166-230) on the augmented state y = [x, th, x_dot, th_dot], action u
     template <class R>
-    __device__ static void f_dyn(const Task& T, const float* c, const R* y, R u, R thdd_prev, R* k, R& thdd_out, const R* tr) {
+    __device__ __forceinline__ static void f_dyn(const Task& T, const float* c, const R* y, R u, R thdd_prev, R* k, R& thdd_out, const R* tr) {
         R th = y[1], x_dot = y[2], th_dot = y[3];
         R sin_th, cos_th;
         if (tr) { sin_th = tr[0]; cos_th = tr[1]; }
@@ -571,21 +588,43 @@ struct QcpT : EnvDefaults<1> {
         k[3] = th_ddot;
         thdd_out = th_ddot;
     }
-    template <class R>
-    __device__ static void dynamics(const Task& T, const float* c, R* s, R* h, const R* act, const R* tr) {
-        // rk4 (:591-655) over [x, th, x_dot, th_dot, u]; u has zero derivative; th_ddot chained through the stages.
-        // The four stage vectors live in VGPRs (16 floats per lane): there is no cross-lane reuse to stage in LDS.
-        R u = act[0], dt = T.dt, dt2 = dt / 2.0f;
-        R k1[4], k2[4], k3[4], k4[4], y[4], a1, a2, a3, a4;
-        f_dyn(T, c, s, u, h[0], k1, a1, tr);
+    // stages 2 .. 4 of the rk4 below and its final combination; ROT: sin / cos of the stage angles by rotation from the
+    // step's own (tr0).  Everything between the first stage and the new state sits inside ONE side of the caller's
+    // wave-uniform branch: the stage vectors stay in registers (arrays that crossed the branch went to scratch)
+    template <bool ROT, class R>
+    __device__ __forceinline__ static void rk_tail(const Task& T, const float* c, R* s, R* h, R u, const R* k1, R a1,
+                                                   const R* tr0) {
+        R dt = T.dt, dt2 = dt / 2.0f;
+        R y[4], trs[2], k2[4], k3[4], k4[4], a2, a3, a4;
         for (int j = 0; j < 4; ++j) y[j] = s[j] + dt2 * k1[j];
-        f_dyn(T, c, y, u, a1, k2, a2, (const R*)nullptr);
+        if (ROT) sincos_rot(tr0[0], tr0[1], dt2 * k1[1], &trs[0], &trs[1]);
+        f_dyn(T, c, y, u, a1, k2, a2, ROT ? (const R*)trs : (const R*)nullptr);
         for (int j = 0; j < 4; ++j) y[j] = s[j] + dt2 * k2[j];
-        f_dyn(T, c, y, u, a2, k3, a3, (const R*)nullptr);
+        if (ROT) sincos_rot(tr0[0], tr0[1], dt2 * k2[1], &trs[0], &trs[1]);
+        f_dyn(T, c, y, u, a2, k3, a3, ROT ? (const R*)trs : (const R*)nullptr);
         for (int j = 0; j < 4; ++j) y[j] = s[j] + dt * k3[j];
-        f_dyn(T, c, y, u, a3, k4, a4, (const R*)nullptr);
+        if (ROT) sincos_rot(tr0[0], tr0[1], dt * k3[1], &trs[0], &trs[1]);
+        f_dyn(T, c, y, u, a3, k4, a4, ROT ? (const R*)trs : (const R*)nullptr);
         for (int j = 0; j < 4; ++j) s[j] = s[j] + dt / 6.0f * (k1[j] + 2.0f * k2[j] + 2.0f * k3[j] + k4[j]);
         h[0] = (a1 + a2 + a3 + a4) / 4.0f;  // mean of the stage th_ddots (:652)
+    }
+    template <class R>
+    __device__ __forceinline__ static void dynamics(const Task& T, const float* c, R* s, R* h, const R* act, const R* tr) {
+        // (force-inlined: with two copies of the later stages the inliner left it a real call -- the constants and the state
+        // then lived in scratch and the kernel ran three times slower)
+        // rk4 (:591-655) over [x, th, x_dot, th_dot, u]; u has zero derivative; th_ddot chained through the stages.
+        // The four stage vectors live in VGPRs (16 floats per lane): there is no cross-lane reuse to stage in LDS.
+        R u = act[0];
+        R k1[4], a1;
+        // sin / cos of the pole angle: of the step's own angle once (tr: the caller holds it from observe()), of the three later
+        // stage angles by rotation from it -- they differ from it by dt/2 or dt times a pole rate, at most ~0.26 rad for
+        // dt <= 4 ms inside (and well beyond) the 20 pi rad/s state box; coarser steps take a fresh sincos per stage
+        R tr0[2];
+        if (tr) { tr0[0] = tr[0]; tr0[1] = tr[1]; }
+        else sincos_fast(s[1], &tr0[0], &tr0[1]);
+        f_dyn(T, c, s, u, h[0], k1, a1, (const R*)tr0);
+        if (T.dt <= 0.004f) rk_tail<true>(T, c, s, h, u, k1, a1, tr0);  // wave-uniform: dt is a kernel argument
+        else rk_tail<false>(T, c, s, h, u, k1, a1, tr0);
     }
     template <class R>
     __device__ static void observe(const R* s, R* o) {  // :107-108

@@ -927,19 +927,25 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
     return v;
 }
 
-template <class E, bool AR, int REC, int NHID>
+// NE = envs per workgroup: 64 (wave 0 owns them) or 256 (waves 0 .. 3 own 64 each, on a SIMD each).  The weight registers allow
+// one workgroup per compute unit at a time either way; the larger one spends a smaller share of a step in its serial part
+// (env step and barriers) and is the shape for batches beyond 128 envs per compute unit.
+template <class E, bool AR, int REC, int NHID, int NE>
 __global__ __launch_bounds__(64 * fnn_waves(NHID)) void k_rollout_fnn(Task T, Dev d, Fnn P, int k_steps, uint64_t reset_seed,
-                                                                uint64_t noise_seed) {
+                                                                      uint64_t noise_seed) {
     static_assert(NHID >= 1 && NHID <= FNN_MAXH, "hidden layers");
-    constexpr bool UNI = false;          // per-env constants: Dev::consts is always kept (k_set_params), read once per launch
-    constexpr int EPW = 64 / fnn_waves(NHID);  // envs a wave evaluates the network for
-    __shared__ __attribute__((aligned(16))) float l_x[64 * FNN_XS];  // what the policy sees: [env][input]
-    __shared__ __attribute__((aligned(16))) float l_h[64 * FNN_W];   // activations of the running layer: [env][unit]
-    __shared__ float l_a[64 * MAXA];                                 // the network's output: [env][A]
+    static_assert(NE == 64 || NE == 256, "envs per workgroup");
+    static_assert(NE / 64 <= fnn_waves(NHID), "one wave per 64 envs owns them");
+    constexpr bool UNI = false;               // per-env constants: Dev::consts is always kept (k_set_params), read once per launch
+    constexpr int EPW = NE / fnn_waves(NHID);  // envs a wave evaluates the network for
+    __shared__ __attribute__((aligned(16))) float l_x[NE * FNN_XS];  // what the policy sees: [env][input]
+    __shared__ __attribute__((aligned(16))) float l_h[NE * FNN_W];   // activations of the running layer: [env][unit]
+    __shared__ float l_a[NE * MAXA];                                 // the network's output: [env][A]
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 64 + lane;  // (wave 0: the env of this lane)
-    const bool envw = wave == 0;
+    const bool envw = wave < NE / 64;         // this wave owns 64 of the workgroup's envs
+    const int er = (envw ? wave : 0) * 64 + lane;  // (env waves: the lane's env inside the workgroup ...
+    const int i = blockIdx.x * NE + er;            //  ... and in the batch)
     const size_t ld = d.ld;
     const size_t rec0 = (size_t)d.traj_t0;
     const bool valid = i < d.n;
@@ -1011,14 +1017,14 @@ __global__ __launch_bounds__(64 * fnn_waves(NHID)) void k_rollout_fnn(Task T, De
                 for (int k = MAXO; k >= 3; --k) x[k] = x[k - 1];
                 x[1] = sn, x[2] = cs;
             }
-            Planes<FNN_XS>::store(l_x, 1, lane * (FNN_XS / 4), x);  // three 16-B stores: row `lane`
+            Planes<FNN_XS>::store(l_x, 1, er * (FNN_XS / 4), x);  // three 16-B stores: the env's row
         }
         ws_barrier();
         // ---- the network for this wave's envs: lane = unit.  Layer by layer over the wave's EPW envs, in groups of QU envs
-        // whose code is one straight-line block (all of them for one and two hidden layers; two at a time, in a rolled loop,
-        // for deeper networks: code size).  Every LDS read below is one address for the whole wave (the env index is
+        // whose code is one straight-line block (four at a time for one and two hidden layers, two for deeper networks, in a rolled loop:
+        // code size).  Every LDS read below is one address for the whole wave (the env index is
         // wave-uniform).  The nonlinearity kind is wave-uniform too: its switch sits outside the group.
-        constexpr int QU = NHID <= 2 ? EPW : 2;
+        constexpr int QU = NHID <= 2 ? 4 : 2;
         auto with_kind = [&](int kind, auto&& body) __attribute__((always_inline)) {
             if (kind == FNN_TANH) body(std::integral_constant<int, FNN_TANH>{});
             else if (kind == FNN_RELU) body(std::integral_constant<int, FNN_RELU>{});
@@ -1102,7 +1108,7 @@ __global__ __launch_bounds__(64 * fnn_waves(NHID)) void k_rollout_fnn(Task T, De
         if (!envw) continue;
         // ---- the policy's action of this lane's env (+ exploration noise)
 #pragma unroll
-        for (int j = 0; j < E::A; ++j) a[j] = fnn_nonlin(P.out_nonlin, l_a[lane * MAXA + j] + P.w[P.off_b[NHID] + j]);
+        for (int j = 0; j < E::A; ++j) a[j] = fnn_nonlin(P.out_nonlin, l_a[er * MAXA + j] + P.w[P.off_b[NHID] + j]);
         if (P.noisy) {
             // NormalActNoiseExplStrat: + std * N(0, 1), keyed like the wrapper noise by (env, episode, step)
             uint4 b = Rng::philox(noise_seed, d.idx0 + (uint32_t)i, RNG_POLICY_NOISE, ((uint64_t)es.epi << 32) | (uint32_t)step);
@@ -1202,7 +1208,7 @@ __global__ __launch_bounds__(64 * fnn_waves(NHID)) void k_rollout_fnn(Task T, De
 // through l_act -- for the families whose C wave is the longer one once it records (QQube: its share of observe() plus the
 // record stores outweigh the Philox block per four steps; measured with the per-role cycle stamps of -DVS_WS_STAMP).
 template <class E, bool UNI, bool AR, int REC, int WS_R, int NE, bool DP, int NR = 2>
-__global__ __launch_bounds__(NR * NE, NR == 3 ? 3 : 1) void k_rollout_ws(Task T, Dev d, int k_steps, uint64_t seed, uint64_t reset_seed,
+__global__ __launch_bounds__(NR * NE, NR == 3 ? 3 : E::WS_MIN_WAVES) void k_rollout_ws(Task T, Dev d, int k_steps, uint64_t seed, uint64_t reset_seed,
                                                         uint64_t epoch0) {
     static_assert(E::FINAL != FINAL_STATE_TIME, "needs the post-step state on the reward side");
     static_assert(NE == 64 || NE == 128 || NE == 256, "envs per workgroup");
@@ -2049,15 +2055,16 @@ void Launch<E>::rollout(vs_env* h, int k, uint64_t seed, uint64_t ep, int rec) {
 
 template <class E>
 void Launch<E>::rollout_fnn(vs_env* h, int k, int rec, uint64_t noise_seed) {
-    dim3 g((unsigned)(h->d.ld / 64));
-#define LF(AR, REC, NH) hipLaunchKernelGGL((k_rollout_fnn<E, AR, REC, NH>), g, dim3(64 * fnn_waves(NH)), 0, h->stream, h->task, h->d, h->fnn, k, h->ar_seed, noise_seed)
-#define LFR(AR, NH) { if (rec == 0) LF(AR, 0, NH); else if (rec == 1) LF(AR, 1, NH); else LF(AR, 2, NH); }
-#define LFA(NH) { if (h->auto_reset) LFR(true, NH) else LFR(false, NH) }
+#define LF(AR, REC, NH, NE) hipLaunchKernelGGL((k_rollout_fnn<E, AR, REC, NH, NE>), dim3((unsigned)(h->d.ld / NE)), dim3(64 * fnn_waves(NH)), 0, h->stream, h->task, h->d, h->fnn, k, h->ar_seed, noise_seed)
+#define LFR(AR, NH, NE) { if (rec == 0) LF(AR, 0, NH, NE); else if (rec == 1) LF(AR, 1, NH, NE); else LF(AR, 2, NH, NE); }
+#define LFA(NH, NE) { if (h->auto_reset) LFR(true, NH, NE) else LFR(false, NH, NE) }
+    // 256-env workgroups beyond 128 envs per compute unit (measured: 65 536 QQube envs, 64 x 64 tanh); one and two hidden layers
+    const bool big = (int64_t)h->d.ld > 128 * (int64_t)h->n_cu;
     switch (h->fnn.n_hidden) {
-        case 1: LFA(1) break;
-        case 2: LFA(2) break;
-        case 3: LFA(3) break;
-        default: LFA(4) break;
+        case 1: if (big) LFA(1, 256) else LFA(1, 64) break;
+        case 2: if (big) LFA(2, 256) else LFA(2, 64) break;
+        case 3: LFA(3, 64) break;
+        default: LFA(4, 64) break;
     }
 #undef LFA
 #undef LFR
