@@ -419,6 +419,7 @@ struct QQT : EnvDefaults<1> {
     static constexpr bool REWARD_SIDE_USES_CONSTS = false;
     static constexpr bool WS_DRAW_P = true;
     static constexpr bool WS_G3 = true;
+    static constexpr int WS_MIN_WAVES = 3;  // its two-role kernel runs three waves per SIMD between 256 and 384 envs per CU (WS_MID)
     enum { C_C0, C_C1, C_C2, C_C3, C_C4, C_KM, C_RM, C_DR, C_DP, C_TH_NEG, C_TH_POS };
     __device__ static void calc_consts(const Task&, const float* p, float* c) {  // _calc_constants :70-87
         float g = p[0], Rm = p[1], km = p[2], mr = p[3], Lr = p[4], Dr = p[5], mp = p[6], Lp = p[7], Dp = p[8];

@@ -293,17 +293,21 @@ __device__ __forceinline__ void load_consts(const Dev& d, int i, float* c, int f
 }
 
 // DomainRandomizer.randomize for one lane (domain_parameter.py:104-132): draw -> clamp; writes the raw params
+__device__ __forceinline__ float draw_one_param(const vs_dp_spec& sp, Rng& g) {
+    float v;
+    if (sp.kind == VS_DP_NORMAL) v = sp.mean + sp.spread * g.normal();
+    else if (sp.kind == VS_DP_UNIFORM) v = g.uniform(sp.mean - sp.spread, sp.mean + sp.spread);
+    else v = g.u01() < sp.aux ? sp.spread : sp.mean;  // Bernoulli(prob_1): val_1 with probability prob_1, else val_0
+    v = fminf(fmaxf(v, sp.clip_lo), sp.clip_up);
+    if (sp.roundint) v = rintf(v);  // torch.round: half to even
+    return v;
+}
 template <class E>
 __device__ __forceinline__ void draw_params(const DrSpecs* dr, Rng& g, float* p) {
     int n = dr->n;
     for (int q = 0; q < n; ++q) {
         const vs_dp_spec sp = dr->s[q];
-        float v;
-        if (sp.kind == VS_DP_NORMAL) v = sp.mean + sp.spread * g.normal();
-        else if (sp.kind == VS_DP_UNIFORM) v = g.uniform(sp.mean - sp.spread, sp.mean + sp.spread);
-        else v = g.u01() < sp.aux ? sp.spread : sp.mean;  // Bernoulli(prob_1): val_1 with probability prob_1, else val_0
-        v = fminf(fmaxf(v, sp.clip_lo), sp.clip_up);
-        if (sp.roundint) v = rintf(v);  // torch.round: half to even
+        const float v = draw_one_param(sp, g);
 #pragma unroll
         for (int k = 0; k < E::P; ++k)
             if (k == sp.param_index) p[k] = v;
@@ -1254,7 +1258,18 @@ __global__ __launch_bounds__(NR * NE, NR == 3 ? 3 : E::WS_MIN_WAVES) void k_roll
     __shared__ float l_stock[STOCK ? SKW * NE : 1];
     __shared__ uint32_t l_stag[STOCK ? NE : 1];
     __shared__ uint32_t l_epi[(STOCK && G3) ? NE : 1];  // G3: the P wave publishes a lane's episode counter at its resets
-    const bool stock_on = STOCK && d.dr_n == 0 && d.pbuf_n == 0;  // wave-uniform
+    // Under a live randomizer (DomainRandWrapperLive: the parameters are redrawn at every reset) the stock entry also holds the
+    // NEXT episode's domain parameters and the constants _calc_constants derives from them: the redraw (Philox + Box-Muller per
+    // parameter + calc_consts: ~11 000 cycles when the P wave runs it for the one or two lanes of its 64 that reset, measured
+    // with -DVS_WS_STAMP) leaves the P wave's critical path like the init-space sample did.  Dynamic LDS, sized by the
+    // launcher only when a randomizer is set:
+    //   [P][NE] the parameters of the entry (a redraw overwrites the randomised ones in place; the others are the lane's
+    //   parameters at the start of the launch and never change) | [K][NE] the constants calc_consts derives from them
+    extern __shared__ float l_dyn[];
+    const bool dr_stock = STOCK && !UNI && d.dr_n > 0 && d.pbuf_n == 0;            // wave-uniform
+    const bool stock_on = STOCK && d.pbuf_n == 0 && (d.dr_n == 0 || dr_stock);     // wave-uniform
+    float* const l_npar = l_dyn;
+    float* const l_ncon = l_dyn + E::P * NE;
     const int wave = threadIdx.x >> 6;
     const int role = wave / (NE / 64);  // 0 P, 1 C, 2 G (NR == 3)
     const int le = threadIdx.x & (NE - 1);  // env slot inside the workgroup
@@ -1325,11 +1340,33 @@ __global__ __launch_bounds__(NR * NE, NR == 3 ? 3 : E::WS_MIN_WAVES) void k_roll
         if (G3) c_epi = __hip_atomic_load(&l_epi[le], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         const bool need = stock_on && valid && c_tag != c_epi;
         if (__builtin_amdgcn_ballot_w64(need) == 0ull) return;
+        if (dr_stock) {
+            // DomainRandWrapperLive.reset of episode c_epi: DomainRandomizer.randomize's draws in their order
+            // (domain_parameter.py:104-132), statement for statement redraw_lane_params', straight into the entry
+            Rng gp(reset_seed, d.idx0 + (uint32_t)i, RNG_PARAM, (uint64_t)c_epi);
+            const int n = d.dr_n;
+            for (int q = 0; q < n; ++q) {
+                const vs_dp_spec sp = d.drv.s[q];
+                const float v = draw_one_param(sp, gp);  // (every lane draws: only the stores are masked)
+                if (need) l_npar[sp.param_index * NE + le] = v;
+            }
+        }
         if (need) {
+            float cs[E::K];  // the constants the init space of episode c_epi is sampled with
+#pragma unroll
+            for (int k = 0; k < E::K; ++k) cs[k] = k < E::KS ? c[k] : 0.f;
+            if (dr_stock) {
+                float p[E::P];
+#pragma unroll
+                for (int k = 0; k < E::P; ++k) p[k] = l_npar[k * NE + le];
+                E::calc_consts(T, p, cs);
+#pragma unroll
+                for (int k = 0; k < E::K; ++k) l_ncon[k * NE + le] = cs[k];
+            }
             // SimPyEnv.reset's init_space.sample_uniform() of episode c_epi: the draw reset_lane_sampled would make
             Rng g(reset_seed, d.idx0 + (uint32_t)i, RNG_INIT, (uint64_t)c_epi);
             float init[E::I];
-            E::sample_init(T, c, g, init);
+            E::sample_init(T, cs, g, init);
 #pragma unroll
             for (int j = 0; j < E::I; ++j) l_stock[j * NE + le] = init[j];
             if (REC && E::TRIG > 0) {
@@ -1441,6 +1478,7 @@ __global__ __launch_bounds__(NR * NE, NR == 3 ? 3 : E::WS_MIN_WAVES) void k_roll
                 Planes<M>::store(l_msg[b & 1][r], NE, le, v);
                 if (AR) {
                     if (__builtin_amdgcn_ballot_w64(fin) != 0ull) {
+                        VS_STAMP(sr0);
                         if (fin) {
 #pragma unroll
                             for (int j = 0; j < E::S; ++j) err_acc |= isnan(s[j]);
@@ -1450,6 +1488,15 @@ __global__ __launch_bounds__(NR * NE, NR == 3 ? 3 : E::WS_MIN_WAVES) void k_roll
                                 const uint32_t tag = __hip_atomic_load(&l_stag[le], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
                                 stocked = tag == epi;
                                 if (stocked) {
+                                    if (dr_stock) {
+                                        // the redrawn parameters and their constants, to where redraw_lane_params puts them
+#pragma unroll
+                                        for (int k = 0; k < E::K; ++k) c[k] = l_ncon[k * NE + le];
+#pragma unroll
+                                        for (int k = 0; k < E::P; ++k) d.params[(size_t)k * ld + i] = l_npar[k * NE + le];
+#pragma unroll
+                                        for (int k = 0; k < E::K; ++k) d.consts[(size_t)k * ld + i] = c[k];
+                                    }
                                     float init[E::I];
 #pragma unroll
                                     for (int j = 0; j < E::I; ++j) init[j] = l_stock[j * NE + le];
@@ -1461,6 +1508,9 @@ __global__ __launch_bounds__(NR * NE, NR == 3 ? 3 : E::WS_MIN_WAVES) void k_roll
                                     E::init_hidden(T, c, nullptr, s, h, false);
                                 }
                             }
+#ifdef VS_WS_STAMP  // resets served from the stock (low word) / drawn on this wave (high word), summed over the launches
+                            if (d.dbg) atomicAdd(d.dbg + ((size_t)(i >> 6) * 3 + 0) * 4, stocked ? 1ull : (1ull << 32));
+#endif
                             if (!stocked) {
                                 // live domain randomisation redraws the lane's parameters here: allowed for the families
                                 // whose C wave does not read constants (use_ws)
@@ -1471,9 +1521,16 @@ __global__ __launch_bounds__(NR * NE, NR == 3 ? 3 : E::WS_MIN_WAVES) void k_roll
                             step = 0;
                             // (after the reads of the stock entry above: the G wave rewrites an entry only once it has seen
                             // a counter beyond the entry's tag)
-                            if (STOCK && G3) __hip_atomic_store(&l_epi[le], epi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            if (STOCK && G3) __hip_atomic_store(&l_epi[le], epi, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                         }
                         if (!UNI) E::act_bounds(c, alo, ahi);
+#ifdef VS_WS_STAMP  // cycles of the reset branch of this wave, and how often it ran (slots of the unused third role when NR == 2)
+                        VS_STAMP(sr1);
+                        if (d.dbg && (threadIdx.x & 63) == 0) {
+                            atomicAdd(d.dbg + ((size_t)(i >> 6) * 3 + 2) * 4 + 0, sr1 - sr0);
+                            atomicAdd(d.dbg + ((size_t)(i >> 6) * 3 + 2) * 4 + 1, 1ull);
+                        }
+#endif
                     }
                 } else {
                     frozen |= done;
@@ -1502,7 +1559,7 @@ __global__ __launch_bounds__(NR * NE, NR == 3 ? 3 : E::WS_MIN_WAVES) void k_roll
 #ifdef VS_WS_STAMP
         if ((threadIdx.x & 63) == 0 && d.dbg) {
             unsigned long long* q = d.dbg + ((size_t)(i >> 6) * 3 + 0) * 4;
-            q[0] = acc0, q[1] = acc1, q[2] = acc2, q[3] = (unsigned long long)nb;
+            q[1] = acc1, q[2] = acc2, q[3] = (unsigned long long)nb;  // (q[0]: the reset counters, accumulated over the launches)
         }
 #endif
 #pragma unroll
@@ -1532,6 +1589,10 @@ __global__ __launch_bounds__(NR * NE, NR == 3 ? 3 : E::WS_MIN_WAVES) void k_roll
         if (STOCK && !G3) {
             c_epi = d.ep_idx[i];
             l_stag[le] = 0xFFFFFFFFu;
+            if (dr_stock) {
+#pragma unroll
+                for (int k = 0; k < E::P; ++k) l_npar[k * NE + le] = d.params[(size_t)k * ld + i];
+            }
         }
         if (!DP && !G3) carry = Rng::philox(seed, d.idx0 + (uint32_t)i, RNG_ACT, blk0);
         // Reward, returns and records of the steps of batch bb, in three passes so that the arithmetic of the WS_R steps --
@@ -1679,6 +1740,10 @@ __global__ __launch_bounds__(NR * NE, NR == 3 ? 3 : E::WS_MIN_WAVES) void k_roll
                 c_epi = d.ep_idx[i];
                 l_stag[le] = 0xFFFFFFFFu;
                 l_epi[le] = c_epi;
+                if (dr_stock) {
+#pragma unroll
+                    for (int k = 0; k < E::P; ++k) l_npar[k * NE + le] = d.params[(size_t)k * ld + i];
+                }
             }
             carry = Rng::philox(seed, d.idx0 + (uint32_t)i, RNG_ACT, blk0);
             auto obs_off = [&](auto full_tag, int bb, int nr) __attribute__((always_inline)) {
@@ -2012,9 +2077,20 @@ template <class E, bool U, bool AR, int NE, int NR = 2>
 static void launch_ws(vs_env* h, int k, uint64_t seed, uint64_t ep, int rec) {
     if constexpr (E::FINAL != FINAL_STATE_TIME) {
         dim3 g((unsigned)(h->d.ld / NE)), b(NR * NE);
+        // dynamic LDS: the live randomizer's part of the reset stock (see the kernel), only when one is set
+        const unsigned dyn = (!U && AR && h->d.dr_n > 0 && h->d.pbuf_n == 0) ? (unsigned)((E::P + E::K) * NE * sizeof(float)) : 0u;
         // R = 4 steps per exchange (measured on the headline config: R = 1 / 2 / 4 -> 68.7 / 64.8 / 62.0 us per 100 steps)
-#define LW(REC) hipLaunchKernelGGL((k_rollout_ws<E, U, AR, REC, 4, NE, (NR == 2 && E::WS_DRAW_P && REC != 0), NR>), g, b, 0, h->stream, h->task, h->d, k, seed, h->ar_seed, ep)
-        if (rec == 0) LW(0); else if (rec == 1) LW(1); else LW(2);
+#define LW(REC)                                                                                                            \
+    {                                                                                                                      \
+        auto kern = k_rollout_ws<E, U, AR, REC, 4, NE, (NR == 2 && E::WS_DRAW_P && REC != 0), NR>;                          \
+        static unsigned char attr_set[64] = {}; /* once per kernel and device */                                           \
+        if (dyn && !attr_set[h->device & 63]) {                                                                            \
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);            \
+            attr_set[h->device & 63] = 1;                                                                                  \
+        }                                                                                                                  \
+        hipLaunchKernelGGL(kern, g, b, dyn, h->stream, h->task, h->d, k, seed, h->ar_seed, ep);                            \
+    }
+        if (rec == 0) LW(0) else if (rec == 1) LW(1) else LW(2)
 #undef LW
     }
 }
