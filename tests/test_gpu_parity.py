@@ -955,6 +955,61 @@ def test_wave_specialised_rollout_kernel_equals_plain_kernel(vs, name, auto_rese
             e.close()
 
 
+@pytest.mark.parametrize("name", ["qq-su", "qcp-su", "qq-st"])
+def test_live_randomizer_stock_equals_plain_kernel(vs, name):
+    """DomainRandWrapperLive on the device with the reference's default randomizer (its first seven parameters: Normal and
+    Uniform draws, clipped) in every shape of k_rollout_ws against k_rollout.  In the wave-specialised kernel a resetting lane
+    takes the next episode's parameters and constants from the reset stock its reward / generator wave pre-draws into LDS, or
+    -- a second reset before the refill: episodes of a few steps make that common here -- draws them itself; either way the
+    parameters, constants, records and episode statistics are those of the plain kernel, bit for bit, across launches that
+    start with an empty stock (1-, 9- and 64-step launches) and with a ragged last workgroup."""
+    L = vs._lib
+    n = 1000
+    kw = dict(KW[name])
+    kw["max_steps"] = 11  # a time-out every 11 steps: several resets per lane and launch, refills every 32 steps
+    specs = vs.create_default_randomizer(vs.ENV_CLASSES[name](**KW[name])).device_specs()[:7]
+    if name != "qcp-su":  # the QQube table is all Normal: make the stream mix one- and two-word draws here too
+        specs[2] = (specs[2][0], "uniform") + tuple(specs[2][2:])
+    assert {sp[1] for sp in specs} >= {"normal", "uniform"}
+    envs = []
+    for variant in ("k_rollout",) + ws_variants(name):
+        e = vs.VecSimEnv(name, n, **kw)
+        e.set_record_mode(2)
+        e.set_params(np.tile(vs.nominal_params(name), (n, 1)))
+        e.set_randomizer(specs)
+        e.set_rollout_variant(variant)
+        assert e.rollout_variant() == variant
+        e.set_auto_reset(True, seed=23)
+        e.reset(seed=5)
+        e.set_traj_capacity(74)
+        t = 0
+        for k in (1, 9, 64):
+            e.set_traj_offset(t)
+            e.step_random(k, seed=6, record=True)
+            t += k
+        envs.append(e)
+    a = envs[0]
+    ta = a.traj(74)
+    pa = a.get(L.VS_PARAMS)
+    rnd = [vs.param_names(name).index(sp[0]) for sp in specs]
+    assert all(len(np.unique(pa[:, k])) > n // 2 for k in rnd)          # every lane drew its own values ...
+    fixed = [k for k in range(pa.shape[1]) if k not in rnd]
+    assert np.array_equal(pa[:, fixed], np.tile(vs.nominal_params(name), (n, 1))[:, fixed].astype(np.float32))  # ... of those only
+    assert a.episode_stats()[0].min() >= 5
+    for b in envs[1:]:
+        tb = b.traj(74)
+        for key in ta:
+            assert np.array_equal(ta[key], tb[key]), (name, key, b.rollout_variant())
+        for which in (L.VS_STATE, L.VS_OBS, L.VS_HIDDEN, L.VS_STEPCOUNT, L.VS_RETURNS, L.VS_REW, L.VS_DONE, L.VS_FAILED,
+                      L.VS_PARAMS, L.VS_CONSTS):
+            assert np.array_equal(a.get(which), b.get(which)), (name, which, b.rollout_variant())
+        for x, y in zip(a.episode_stats(), b.episode_stats()):
+            assert np.array_equal(x, y)
+        assert b.error_count() == 0
+    for e in envs:
+        e.close()
+
+
 def test_step_jacobians_against_the_forks_autograd(vs, golden_dir):
     """vs_step_jac against tests/golden/jac_qcp_su.npz: d(s', r) / d(s, a) of QCartPoleSwingUpSim as the fork computes them
     with torch.autograd.grad through its step_diff_state (P/sampling/rollout.py:832-837, quanser_cartpole.py:257-431), float64,
