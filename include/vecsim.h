@@ -282,6 +282,12 @@ int vs_step_random(vs_handle h, uint64_t seed, int k_steps, int record);
  * Not available with a wrapper pipeline on the handle or for the discrete-action family (VS_ERR_STATE / VS_ERR_ARG). */
 int vs_set_policy_fnn(vs_handle h, const vs_fnn_desc* desc, const float* params, int64_t n_params);
 int vs_step_policy(vs_handle h, int k_steps, int record, uint64_t noise_seed);
+/* the shape vs_step_policy evaluates the network in: -1 automatic (default), 0 the network of 64 envs spread over the 8 waves
+ * of a 64-env workgroup (vector ALU, lane = hidden unit), 1 the same in 256-env workgroups, 2 256-env workgroups with the
+ * hidden layers on the matrix cores (v_mfma_f32_32x32x2_f32: fp32 in, fp32 out; one and two hidden layers -- deeper networks
+ * run shape 0 whatever is asked).  No counterpart in the reference (which evaluates the torch module, P/sampling/rollout.py:203-219);
+ * the shapes differ in the summation order of a layer only. */
+int vs_set_policy_shape(vs_handle h, int shape);
 /* The action stream of vs_step_random is Philox(seed; global env index, absolute step index); the handle counts the
  * steps it has taken.  vs_seek_random repositions that counter (0 = start of a fresh batch of rollouts). */
 int vs_seek_random(vs_handle h, uint64_t step_index);

@@ -748,6 +748,12 @@ int vs_set_rollout_variant(vs_handle h, int variant) {
     return VS_OK;
 }
 
+int vs_set_policy_shape(vs_handle h, int shape) {
+    if (!h || shape < -1 || shape > 2) return fail(h, VS_ERR_ARG, "vs_set_policy_shape: -1 (automatic) or 0 .. 2");
+    h->policy_shape = shape;
+    return VS_OK;
+}
+
 int vs_rollout_variant(vs_handle h) {
     if (!h) return VS_ERR_ARG;
     int var = 0;

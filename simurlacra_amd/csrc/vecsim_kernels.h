@@ -934,17 +934,33 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
 // NE = envs per workgroup: 64 (wave 0 owns them) or 256 (waves 0 .. 3 own 64 each, on a SIMD each).  The weight registers allow
 // one workgroup per compute unit at a time either way; the larger one spends a smaller share of a step in its serial part
 // (env step and barriers) and is the shape for batches beyond 128 envs per compute unit.
-template <class E, bool AR, int REC, int NHID, int NE>
+// MF: the hidden layers on the matrix cores (v_mfma_f32_32x32x2_f32, fp32 in and out: the policy's numerics stay fp32), for
+// 256-env workgroups of 8 waves and one or two hidden layers.  A wave evaluates the network for 32 envs as D = W x X with
+// rows = units (two tiles of 32), columns = its 32 envs, K = the layer's inputs two at a time:
+//   * A operand (weights): lane l holds W[unit 32u + l % 32][input 2kk + l / 32] -- stationary in VGPRs for the launch;
+//   * B operand, first layer: the env's input row from LDS, lane l reads x[env l % 32][2kk + l / 32];
+//   * accumulator register r of lane l is D[unit 8 (r / 4) + 4 (l / 32) + r % 4][env l % 32] (scratch/ubench/mfma_layout.hip):
+//     taken as the B operand of K-step r of the NEXT layer it supplies inputs (8 (r / 4) + r % 4) and (.. + 4) -- the sum over K
+//     does not care about the order, so the next layer's weights are simply loaded in that order and the activations never
+//     leave the registers between two layers (bias = the accumulator's initial value, nonlinearity in place);
+//   * output layer: 32 products per lane against the weights in accumulator order, the two half-waves added through LDS.
+// 64 x 64 hidden-to-hidden: 64 MFMAs of 64 cycles per wave and 32 envs instead of 16 broadcast LDS reads + 64 FMAs per env.
+typedef float fnn_acc __attribute__((ext_vector_type(16)));
+template <class E, bool AR, int REC, int NHID, int NE, bool MF = false>
 __global__ __launch_bounds__(64 * fnn_waves(NHID)) void k_rollout_fnn(Task T, Dev d, Fnn P, int k_steps, uint64_t reset_seed,
                                                                       uint64_t noise_seed) {
     static_assert(NHID >= 1 && NHID <= FNN_MAXH, "hidden layers");
     static_assert(NE == 64 || NE == 256, "envs per workgroup");
     static_assert(NE / 64 <= fnn_waves(NHID), "one wave per 64 envs owns them");
+    static_assert(!MF || (NE == 256 && NHID <= 2), "matrix-core path: 8 waves x 32 envs, one or two hidden layers");
     constexpr bool UNI = false;               // per-env constants: Dev::consts is always kept (k_set_params), read once per launch
     constexpr int EPW = NE / fnn_waves(NHID);  // envs a wave evaluates the network for
     __shared__ __attribute__((aligned(16))) float l_x[NE * FNN_XS];  // what the policy sees: [env][input]
-    __shared__ __attribute__((aligned(16))) float l_h[NE * FNN_W];   // activations of the running layer: [env][unit]
+    __shared__ __attribute__((aligned(16))) float l_h[MF ? 4 : NE * FNN_W];   // activations of the running layer: [env][unit]
     __shared__ float l_a[NE * MAXA];                                 // the network's output: [env][A]
+    __shared__ __attribute__((aligned(16))) float l_bias[MF ? NHID * FNN_W : 4];   // MF: hidden biases and output weights, read
+    __shared__ __attribute__((aligned(16))) float l_wo[MF ? MAXA * FNN_W : 4];     //     in accumulator order every step
+    __shared__ float l_part[MF ? 64 * fnn_waves(NHID) * 2 : 4];                    //     half-wave partial sums of the output layer
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
     const bool envw = wave < NE / 64;         // this wave owns 64 of the workgroup's envs
@@ -956,17 +972,50 @@ __global__ __launch_bounds__(64 * fnn_waves(NHID)) void k_rollout_fnn(Task T, De
 
     // ---- unit `lane` of every layer: its weight rows, for the whole launch
     float w1[FNN_XS], wh[NHID > 1 ? NHID - 1 : 1][FNN_W], bh[NHID], wo[E::A];
+    float a1[2][FNN_XS / 2], a2[2][2][16];  // MF: the A operands of the two layers (see above)
+    const int half = lane >> 5, col = lane & 31;
+    if constexpr (!MF) {
 #pragma unroll
-    for (int k = 0; k < FNN_XS; ++k) w1[k] = k < P.in_dim ? P.w[P.off_w[0] + k * FNN_W + lane] : 0.f;
+        for (int k = 0; k < FNN_XS; ++k) w1[k] = k < P.in_dim ? P.w[P.off_w[0] + k * FNN_W + lane] : 0.f;
 #pragma unroll
-    for (int l = 1; l < NHID; ++l) {
+        for (int l = 1; l < NHID; ++l) {
 #pragma unroll
-        for (int k = 0; k < FNN_W; ++k) wh[l - 1][k] = P.w[P.off_w[l] + k * FNN_W + lane];
+            for (int k = 0; k < FNN_W; ++k) wh[l - 1][k] = P.w[P.off_w[l] + k * FNN_W + lane];
+        }
+#pragma unroll
+        for (int l = 0; l < NHID; ++l) bh[l] = P.w[P.off_b[l] + lane];
+#pragma unroll
+        for (int j = 0; j < E::A; ++j) wo[j] = P.w[P.off_w[NHID] + j * FNN_W + lane];
+    } else {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+#pragma unroll
+            for (int kk = 0; kk < FNN_XS / 2; ++kk) {
+                const int k = 2 * kk + half;
+                a1[u][kk] = k < P.in_dim ? P.w[P.off_w[0] + k * FNN_W + 32 * u + col] : 0.f;
+            }
+        }
+        if constexpr (NHID > 1) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+#pragma unroll
+                for (int up = 0; up < 2; ++up) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int k = 32 * up + 8 * (r / 4) + 4 * half + (r % 4);
+                        a2[u][up][r] = P.w[P.off_w[1] + k * FNN_W + 32 * u + col];
+                    }
+                }
+            }
+        }
+        // biases and output weights into LDS (the first barrier of the step loop comes before their first use)
+        if (threadIdx.x < FNN_W) {
+#pragma unroll
+            for (int l = 0; l < NHID; ++l) l_bias[l * FNN_W + threadIdx.x] = P.w[P.off_b[l] + threadIdx.x];
+#pragma unroll
+            for (int j = 0; j < E::A; ++j) l_wo[j * FNN_W + threadIdx.x] = P.w[P.off_w[NHID] + j * FNN_W + threadIdx.x];
+        }
     }
-#pragma unroll
-    for (int l = 0; l < NHID; ++l) bh[l] = P.w[P.off_b[l] + lane];
-#pragma unroll
-    for (int j = 0; j < E::A; ++j) wo[j] = P.w[P.off_w[NHID] + j * FNN_W + lane];
 
     // ---- env state of the lane: wave 0 only (the other waves never touch it)
     float c[E::K], s[E::S], h[E::H > 0 ? E::H : 1], a[E::A], ob[E::O];
@@ -1029,6 +1078,87 @@ __global__ __launch_bounds__(64 * fnn_waves(NHID)) void k_rollout_fnn(Task T, De
         // code size).  Every LDS read below is one address for the whole wave (the env index is
         // wave-uniform).  The nonlinearity kind is wave-uniform too: its switch sits outside the group.
         constexpr int QU = NHID <= 2 ? 4 : 2;
+        if constexpr (MF) {
+            const int e0 = wave * 32;  // this wave's 32 envs
+            // (a layer of at most 32 units has an all-zero second tile: zero weights and biases, and the next layer's weights
+            // for it are zero too -- it is skipped, wave-uniformly)
+            const bool wide0 = P.hidden[0] > 32, wide1 = NHID > 1 && P.hidden[NHID > 1 ? 1 : 0] > 32;
+            auto nonlin16 = [&](int kind, fnn_acc* v, bool wide) __attribute__((always_inline)) {  // kind, wide: wave-uniform
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    if (u == 1 && !wide) continue;
+                    if (kind == FNN_TANH) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            // tanh_fast with the bare v_rcp_f32 (1 ulp): 64 of these per env step and lane
+                            const float x = v[u][r];
+                            const float t = __builtin_amdgcn_exp2f(-2.885390081777927f * fabsf(x));
+                            v[u][r] = copysignf((1.0f - t) * __builtin_amdgcn_rcpf(1.0f + t), x);
+                        }
+                    } else if (kind != FNN_ID) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) v[u][r] = fnn_nonlin(kind, v[u][r]);
+                    }
+                }
+            };
+            auto bias_init = [&](int l, fnn_acc* v) __attribute__((always_inline)) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float4 b4 = *reinterpret_cast<const float4*>(l_bias + l * FNN_W + 32 * u + 8 * g + 4 * half);
+                        v[u][4 * g] = b4.x, v[u][4 * g + 1] = b4.y, v[u][4 * g + 2] = b4.z, v[u][4 * g + 3] = b4.w;
+                    }
+            };
+            fnn_acc h1[2], h2[2];
+            bias_init(0, h1);
+            float xb1[FNN_XS / 2];
+#pragma unroll
+            for (int kk = 0; kk < FNN_XS / 2; ++kk) xb1[kk] = l_x[(e0 + col) * FNN_XS + 2 * kk + half];
+#pragma unroll
+            for (int kk = 0; kk < FNN_XS / 2; ++kk) {
+                if (2 * kk >= P.in_dim) continue;  // (wave-uniform: the padding inputs)
+                h1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[0][kk], xb1[kk], h1[0], 0, 0, 0);
+                if (wide0) h1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[1][kk], xb1[kk], h1[1], 0, 0, 0);
+            }
+            nonlin16(P.hid_nonlin[0], h1, wide0);
+            if constexpr (NHID > 1) {
+                bias_init(1, h2);
+#pragma unroll
+                for (int up = 0; up < 2; ++up) {
+                    if (up == 1 && !wide0) continue;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float xb = h1[up][r];
+                        h2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[0][up][r], xb, h2[0], 0, 0, 0);
+                        if (wide1) h2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[1][up][r], xb, h2[1], 0, 0, 0);
+                    }
+                }
+                nonlin16(P.hid_nonlin[1], h2, wide1);
+            }
+            fnn_acc* const hl = NHID > 1 ? h2 : h1;
+            const bool widel = NHID > 1 ? wide1 : wide0;
+#pragma unroll
+            for (int j = 0; j < E::A; ++j) {
+                float part = 0.f;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    if (u == 1 && !widel) continue;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float4 w4 = *reinterpret_cast<const float4*>(l_wo + j * FNN_W + 32 * u + 8 * g + 4 * half);
+                        part = fmaf(w4.x, hl[u][4 * g], part);
+                        part = fmaf(w4.y, hl[u][4 * g + 1], part);
+                        part = fmaf(w4.z, hl[u][4 * g + 2], part);
+                        part = fmaf(w4.w, hl[u][4 * g + 3], part);
+                    }
+                }
+                // the other half-wave holds the other 32 units of the same env: add through LDS (one wave, in order)
+                l_part[(wave * 64 + lane) * 2 + (j & 1)] = part;
+                const float other = l_part[(wave * 64 + (lane ^ 32)) * 2 + (j & 1)];
+                if (half == 0) l_a[(e0 + col) * MAXA + j] = part + other;
+            }
+        }
         auto with_kind = [&](int kind, auto&& body) __attribute__((always_inline)) {
             if (kind == FNN_TANH) body(std::integral_constant<int, FNN_TANH>{});
             else if (kind == FNN_RELU) body(std::integral_constant<int, FNN_RELU>{});
@@ -1049,7 +1179,7 @@ __global__ __launch_bounds__(64 * fnn_waves(NHID)) void k_rollout_fnn(Task T, De
                 l_h[e * FNN_W + lane] = hv;
             }
         };
-        with_kind(P.hid_nonlin[0], [&](auto kind) __attribute__((always_inline)) {
+        if constexpr (!MF) with_kind(P.hid_nonlin[0], [&](auto kind) __attribute__((always_inline)) {
 #pragma unroll 1
             for (int g = 0; g < EPW / QU; ++g) {
                 const int e0 = wave * EPW + g * QU;
@@ -1105,9 +1235,9 @@ __global__ __launch_bounds__(64 * fnn_waves(NHID)) void k_rollout_fnn(Task T, De
                 }
             });
         };
-        if constexpr (NHID > 1) hidden_layer(std::integral_constant<int, 1>{});
-        if constexpr (NHID > 2) hidden_layer(std::integral_constant<int, 2>{});
-        if constexpr (NHID > 3) hidden_layer(std::integral_constant<int, 3>{});
+        if constexpr (!MF && NHID > 1) hidden_layer(std::integral_constant<int, 1>{});
+        if constexpr (!MF && NHID > 2) hidden_layer(std::integral_constant<int, 2>{});
+        if constexpr (!MF && NHID > 3) hidden_layer(std::integral_constant<int, 3>{});
         ws_barrier();
         if (!envw) continue;
         // ---- the policy's action of this lane's env (+ exploration noise)
@@ -1967,6 +2097,7 @@ struct vs_env {
     float* d_ring = nullptr;      // ActDelayWrapper ring (Pipe::ring)
     vs::Fnn fnn{};                // vs_set_policy_fnn: the network vs_step_policy evaluates (fnn.w == nullptr: none)
     int rollout_variant = -1;     // vs_set_rollout_variant: -1 automatic, 0 k_rollout, 1 k_rollout_ws<256>, 2 k_rollout_ws<64>, 3 / 4 the three-role kernel in 64 / 256-env workgroups
+    int policy_shape = -1;        // vs_set_policy_shape: -1 automatic, 0 / 1: k_rollout_fnn in 64- / 256-env workgroups, 2: 256-env + matrix cores
     int n_cu = 256;               // compute units of the device (256 on MI355X)
     bool auto_reset = false;
     uint64_t ar_seed = 0;
@@ -2131,16 +2262,24 @@ void Launch<E>::rollout(vs_env* h, int k, uint64_t seed, uint64_t ep, int rec) {
 
 template <class E>
 void Launch<E>::rollout_fnn(vs_env* h, int k, int rec, uint64_t noise_seed) {
-#define LF(AR, REC, NH, NE) hipLaunchKernelGGL((k_rollout_fnn<E, AR, REC, NH, NE>), dim3((unsigned)(h->d.ld / NE)), dim3(64 * fnn_waves(NH)), 0, h->stream, h->task, h->d, h->fnn, k, h->ar_seed, noise_seed)
-#define LFR(AR, NH, NE) { if (rec == 0) LF(AR, 0, NH, NE); else if (rec == 1) LF(AR, 1, NH, NE); else LF(AR, 2, NH, NE); }
-#define LFA(NH, NE) { if (h->auto_reset) LFR(true, NH, NE) else LFR(false, NH, NE) }
-    // 256-env workgroups beyond 128 envs per compute unit (measured: 65 536 QQube envs, 64 x 64 tanh); one and two hidden layers
-    const bool big = (int64_t)h->d.ld > 128 * (int64_t)h->n_cu;
+#define LF(AR, REC, NH, NE, MF) hipLaunchKernelGGL((k_rollout_fnn<E, AR, REC, NH, NE, MF>), dim3((unsigned)(h->d.ld / NE)), dim3(64 * fnn_waves(NH)), 0, h->stream, h->task, h->d, h->fnn, k, h->ar_seed, noise_seed)
+#define LFR(AR, NH, NE, MF) { if (rec == 0) LF(AR, 0, NH, NE, MF); else if (rec == 1) LF(AR, 1, NH, NE, MF); else LF(AR, 2, NH, NE, MF); }
+#define LFA(NH, NE, MF) { if (h->auto_reset) LFR(true, NH, NE, MF) else LFR(false, NH, NE, MF) }
+    // 256-env workgroups beyond 128 envs per compute unit, with the hidden layers on the matrix cores (one and two hidden layers;
+    // measured: 65 536 QQube envs, 64 x 64 tanh).  VS_FNN_SHAPE=64|256|mfma pins the shape (experiments, tests).
+    static const char* force = getenv("VS_FNN_SHAPE");
+    // 0: 64-env workgroups (the network of 64 envs on 8 waves: 4.4 us per step while every workgroup has a compute unit),
+    // 1: 256-env workgroups on the vector ALU, 2: 256-env workgroups on the matrix cores (7.8 us per step of up to 256 envs
+    // per compute unit: the choice beyond 64 envs per compute unit; profiles/r02_table_policy_kernel.txt)
+    int shape = (int64_t)h->d.ld > 64 * (int64_t)h->n_cu ? 2 : 0;
+    if (force) shape = force[0] == 'm' ? 2 : force[0] == '2' ? 1 : 0;
+    if (h->policy_shape >= 0) shape = h->policy_shape;
+    if (h->fnn.n_hidden > 2) shape = 0;
     switch (h->fnn.n_hidden) {
-        case 1: if (big) LFA(1, 256) else LFA(1, 64) break;
-        case 2: if (big) LFA(2, 256) else LFA(2, 64) break;
-        case 3: LFA(3, 64) break;
-        default: LFA(4, 64) break;
+        case 1: if (shape == 2) LFA(1, 256, true) else if (shape == 1) LFA(1, 256, false) else LFA(1, 64, false) break;
+        case 2: if (shape == 2) LFA(2, 256, true) else if (shape == 1) LFA(2, 256, false) else LFA(2, 64, false) break;
+        case 3: LFA(3, 64, false) break;
+        default: LFA(4, 64, false) break;
     }
 #undef LFA
 #undef LFR

@@ -410,6 +410,13 @@ class VecSimEnv:
         fused kernel (bit-identical results every way)"""
         self._check(self._lib.vs_set_rollout_variant(self._h, self._VARIANTS[variant]), "vs_set_rollout_variant")
 
+    _POLICY_SHAPES = {None: -1, "64": 0, "256": 1, "mfma": 2}
+
+    def set_policy_shape(self, shape=None):
+        """None: automatic; '64' / '256': the in-kernel policy network on the vector ALU in 64- / 256-env workgroups; 'mfma': 256-env
+        workgroups with the hidden layers on the matrix cores (one and two hidden layers).  Same network, another summation order."""
+        self._check(self._lib.vs_set_policy_shape(self._h, self._POLICY_SHAPES[shape]), "vs_set_policy_shape")
+
     def rollout_variant(self):
         """the kernel vs_step_random launches for the current configuration"""
         return {0: "k_rollout", 1: "k_rollout_ws", 2: "k_rollout_ws64", 3: "k_rollout_ws64g", 4: "k_rollout_ws256g"}[self._lib.vs_rollout_variant(self._h)]
