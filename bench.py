@@ -58,6 +58,7 @@ ACT_HI = {"omo": 30.0, "bob": 29.43, "qq-su": 4.5, "qcp-su": 6.0, "qbb": 3.0, "q
           "bob-d": 29.43}
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_ACHIEVABLE_GBS = 6290.0  # what a float4 copy reaches there (79 % of spec)
+MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 matrix rate (v_mfma_f32_32x32x2_f32: 64 FLOP/clk/SIMD = the fp32 vector rate), same guide
 DEFAULT_CHUNK = 400  # env steps per launch: the fixed cost of a launch (dispatch, pipeline fill and drain: ~6 us) is 3 % of it
 RECORD_BUFFER_BYTES = 1.25 * 2 ** 30  # rotating record buffer: > 1 GiB, several times the 256 MiB Infinity Cache
 
@@ -543,6 +544,35 @@ def roofline(args, env, local_rank, d, n, chunk, ms_region=None):
             del act
         except Exception as exc:  # the headline must not depend on this leg
             roof["large_n"] = {"error": repr(exc)}
+    if args.mode == "fused" and args.env == "qq-su":
+        # the policy-in-the-loop point of the path (rollout.py:203-219 with an FNNPolicy): vs_step_policy, the network evaluated
+        # inside the fused kernel, hidden layers as fp32 MFMA -- its bound is the fp32 matrix / vector rate, not HBM
+        try:
+            hidden, ksteps = [64, 64], 200
+            pe = vs.VecSimEnv(args.env, n, device=local_rank, **ENV_KW[args.env])
+            pe.set_params(np.tile(vs.nominal_params(args.env), (n, 1)))
+            net = vs.FNN(d["O"], d["A"], hidden, torch.tanh)
+            pe.set_policy_fnn(net.param_values, hidden, "tanh", noise_std=np.full(d["A"], 0.1, dtype=np.float32))
+            pe.set_auto_reset(True, seed=5)
+            pe.reset(seed=6)
+            pe.set_traj_capacity(ksteps)
+            for _ in range(3):
+                pe.step_policy(ksteps, record=True, noise_seed=3)
+            pe.sync()
+            pe.timer_start()
+            for _ in range(10):
+                pe.step_policy(ksteps, record=True, noise_seed=3)
+            msp = pe.timer_stop() / 10
+            dims = [d["O"]] + hidden + [d["A"]]
+            flop = 2 * sum(a * b for a, b in zip(dims[:-1], dims[1:]))  # per env step: the network's FMAs only
+            tf = flop * n * ksteps / (msp * 1e-3) / 1e12
+            roof["policy_fnn"] = {"kernel": "k_rollout_fnn (256-env workgroups, v_mfma_f32_32x32x2_f32)", "net": "6-64-64-1 tanh + exploration noise",
+                                  "bound": "mfma", "dtype": "f32", "us_per_env_step_of_the_batch": msp * 1e3 / ksteps,
+                                  "env_steps_per_s": n * ksteps / (msp * 1e-3), "flop_per_env_step": flop, "achieved": tf,
+                                  "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TFLOPS}
+            pe.close()
+        except Exception as exc:  # the headline must not depend on this leg
+            roof["policy_fnn"] = {"error": repr(exc)}
     roof["note"] = ("at 65 536 envs there is one wave of envs per SIMD: the fused kernel runs three cooperating waves per 64 envs "
                     "(k_rollout_ws: physics | reward + records | action generator + first record plane); its record stream is a "
                     "pure write stream, whose ceiling on this GPU is `write_kernel_GBs`, not the 8 TB/s of `peak` (DESIGN.md "

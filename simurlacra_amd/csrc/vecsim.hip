@@ -260,7 +260,7 @@ static int mixed_upload(vs_mixed* m, const float* const* acts, const int64_t* en
 
 extern "C" {
 
-int vs_version(void) { return 210; }
+int vs_version(void) { return 211; }
 
 static int record_width(int t, int mode) {
     const EnvInfo& e = ENV_INFO[t];
@@ -749,7 +749,7 @@ int vs_set_rollout_variant(vs_handle h, int variant) {
 }
 
 int vs_set_policy_shape(vs_handle h, int shape) {
-    if (!h || shape < -1 || shape > 3) return fail(h, VS_ERR_ARG, "vs_set_policy_shape: -1 (automatic) or 0 .. 3");
+    if (!h || shape < -1 || shape > 2) return fail(h, VS_ERR_ARG, "vs_set_policy_shape: -1 (automatic) or 0 .. 2");
     h->policy_shape = shape;
     return VS_OK;
 }

@@ -395,10 +395,9 @@ struct EpStat {
 // No memory traffic unless live domain randomisation rewrites the lane's params/constants or the episode log is on.
 template <class E, bool UNI>
 __device__ __forceinline__ void auto_reset(const Task& T, const Dev& d, bool fin, int i, uint64_t seed, float* c,
-                                           float* s, float* h, int& step, float& ret, bool& yielded, EpStat& es,
-                                           bool logs = true) {  // logs: this lane appends to the episode log (k_rollout_fnn_w)
+                                           float* s, float* h, int& step, float& ret, bool& yielded, EpStat& es) {
     if (__builtin_amdgcn_ballot_w64(fin) == 0ull) return;
-    if (d.log_episodes) append_episode(d, fin && logs, i, ret, step);
+    if (d.log_episodes) append_episode(d, fin, i, ret, step);
     if (fin) {
         es.count += 1u;
         es.retsum += ret;
@@ -882,7 +881,6 @@ __device__ __forceinline__ void ws_barrier() {
 // scalar loads, units split over the waves -- spent its time waiting for SMEM (7.3 us per step at <= 16 384 envs).
 constexpr int FNN_MAXH = 4;   // hidden layers
 constexpr int FNN_W = 64;     // padded width of a hidden layer = lanes of a wave
-constexpr int FNN_W_SKEW = 6;  // k_rollout_fnn_w: initial delay of the upper four waves, x 512 cycles
 constexpr int FNN_XS = 12;    // padded width of the input row (in_dim <= MAXO + 1 = 9): three 16-B reads
 // waves per 64 envs: 8 (two per SIMD, 256 VGPRs each) while one 64-wide hidden-to-hidden weight row set fits beside the env
 // state; 4 (one per SIMD, 512 VGPRs) for three and four hidden layers, whose 128 / 192 weight registers would spill
@@ -1100,10 +1098,11 @@ __global__ __launch_bounds__(64 * fnn_waves(NHID)) void k_rollout_fnn(Task T, De
                     if (kind == FNN_TANH) {
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
-                            // tanh_fast with the bare v_rcp_f32 (1 ulp): 64 of these per env step and lane
-                            const float x = v[u][r];
-                            const float t = __builtin_amdgcn_exp2f(-2.885390081777927f * fabsf(x));
-                            v[u][r] = copysignf((1.0f - t) * __builtin_amdgcn_rcpf(1.0f + t), x);
+                            // 1 - 2 / (1 + exp(2x)) with the bare v_rcp_f32 (1 ulp): mul, exp, add, rcp, fma -- 64 of these per
+                            // env step and lane, on the same issue budget as the MFMAs (two instructions less than the
+                            // (1 - t) / (1 + t) form of tanh_fast; exp -> inf / 0 gives +-1, NaN stays NaN; same 1e-7 absolute error)
+                            const float t = __builtin_amdgcn_exp2f(2.885390081777927f * v[u][r]);
+                            v[u][r] = fmaf(-2.0f, __builtin_amdgcn_rcpf(1.0f + t), 1.0f);
                         }
                     } else if (kind != FNN_ID) {
 #pragma unroll
@@ -1304,259 +1303,6 @@ __global__ __launch_bounds__(64 * fnn_waves(NHID)) void k_rollout_fnn(Task T, De
         E::observe(s, ob);
     }
     if (!envw) return;
-#pragma unroll
-    for (int j = 0; j < E::S; ++j) d.state[j * ld + i] = s[j];
-#pragma unroll
-    for (int j = 0; j < E::H; ++j) d.hidden[j * ld + i] = h[j];
-#pragma unroll
-    for (int j = 0; j < E::O; ++j) d.obs[j * ld + i] = ob[j];
-    d.step[i] = step;
-    d.ret[i] = ret;
-    d.rew[i] = rew;
-    d.done[i] = done;
-    d.failed[i] = failed;
-    if (E::FINAL != FINAL_NONE) d.yielded[i] = yielded;
-    d.ep_idx[i] = es.epi;
-    d.es_count[i] = es.count;
-    d.es_retsum[i] = es.retsum;
-    d.es_lensum[i] = es.lensum;
-}
-
-// k_rollout_fnn_w: the matrix-core policy kernel without a workgroup barrier in the step loop.  k_rollout_fnn<.., MF> runs the
-// step of 256 envs as  observation rows -> barrier -> network (8 waves x 32 envs) -> barrier -> env step (4 waves x 64 envs):
-// every wave of a compute unit is in the same phase, so the matrix pipe idles through the nonlinearities and the env step, and the
-// vector ALU through the MFMAs.  Here a wave OWNS 32 envs from observation to env step: lanes l and l + 32 both carry env
-// l % 32 (the env step costs a wave the same issue slots for 32 as for 64 lanes, and at one wave per SIMD the four env waves
-// used half of them) -- so
-//   * the first layer's B operand  x[env l % 32][2 kk + l / 32]  is a select between two of the lane's own registers,
-//   * the two half-waves' partial sums of the output layer meet in a wave-private LDS slot (one wave: in order, no barrier),
-//     and  part + other  is the same float in both halves (commutative), hence the same action, step and reset in both,
-//   * only the lower half-wave writes (records, done bits, episode log, final buffers),
-// and nothing in the loop waits for another wave.  The two waves of a SIMD (w and w + 4) are started half a step apart
-// (`skew`: the upper four sleep first), so one runs its MFMAs while the other runs tanh / env step / features on the vector ALU.
-// Same A operands, accumulation order and output sums as the MF path of k_rollout_fnn: bit-identical actions.
-template <class E, bool AR, int REC, int NHID>
-__global__ __launch_bounds__(512) void k_rollout_fnn_w(Task T, Dev d, Fnn P, int k_steps, uint64_t reset_seed, uint64_t noise_seed,
-                                                       int skew) {
-    static_assert(NHID == 1 || NHID == 2, "matrix-core path: one or two hidden layers");
-    constexpr bool UNI = false;
-    constexpr int NE = 256, NW = 8;
-    __shared__ __attribute__((aligned(16))) float l_bias[NHID * FNN_W];
-    __shared__ __attribute__((aligned(16))) float l_wo[MAXA * FNN_W];
-    __shared__ float l_part[NW * MAXA * 64];
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int lane = threadIdx.x & 63;
-    const int half = lane >> 5, col = lane & 31;
-    const bool writer = half == 0;
-    const int i = blockIdx.x * NE + wave * 32 + col;
-    const size_t ld = d.ld;
-    const size_t rec0 = (size_t)d.traj_t0;
-    const bool valid = i < d.n;
-
-    float a1[2][FNN_XS / 2], a2[2][2][16];  // the A operands (k_rollout_fnn, MF)
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-#pragma unroll
-        for (int kk = 0; kk < FNN_XS / 2; ++kk) {
-            const int k = 2 * kk + half;
-            a1[u][kk] = k < P.in_dim ? P.w[P.off_w[0] + k * FNN_W + 32 * u + col] : 0.f;
-        }
-    }
-    if constexpr (NHID > 1) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-#pragma unroll
-            for (int up = 0; up < 2; ++up) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int k = 32 * up + 8 * (r / 4) + 4 * half + (r % 4);
-                    a2[u][up][r] = P.w[P.off_w[1] + k * FNN_W + 32 * u + col];
-                }
-            }
-        }
-    }
-    if (threadIdx.x < FNN_W) {
-#pragma unroll
-        for (int l = 0; l < NHID; ++l) l_bias[l * FNN_W + threadIdx.x] = P.w[P.off_b[l] + threadIdx.x];
-#pragma unroll
-        for (int j = 0; j < E::A; ++j) l_wo[j * FNN_W + threadIdx.x] = P.w[P.off_w[NHID] + j * FNN_W + threadIdx.x];
-    }
-
-    float c[E::K], s[E::S], h[E::H > 0 ? E::H : 1], a[E::A], ob[E::O];
-    float alo[E::A], ahi[E::A];
-    load_consts<E, UNI>(d, i, c, 0, E::KS);
-#pragma unroll
-    for (int j = 0; j < E::S; ++j) s[j] = d.state[j * ld + i];
-#pragma unroll
-    for (int j = 0; j < E::H; ++j) h[j] = d.hidden[j * ld + i];
-    int step = d.step[i];
-    float ret = d.ret[i], rew = d.rew[i];
-    bool yielded = E::FINAL != FINAL_NONE ? d.yielded[i] != 0 : false;
-    bool frozen = !AR && d.done[i] != 0;
-    bool done = d.done[i] != 0, failed = d.failed[i] != 0;
-    EpStat es{d.ep_idx[i], d.es_count[i], d.es_retsum[i], d.es_lensum[i]};
-    DoneBits db;
-    db.w = 0u;
-    E::act_bounds(c, alo, ahi);
-    E::observe(s, ob);
-    if (REC) db.begin(d, i, rec0);
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // (see rollout_body: nothing pending at the loop header)
-    __syncthreads();                     // l_bias / l_wo; the only workgroup barrier of the kernel
-    if (wave >= NW / 2) {
-        for (int q = 0; q < skew; ++q) __builtin_amdgcn_s_sleep(8);  // ~ 512 cycles each
-    }
-    const bool wide0 = P.hidden[0] > 32, wide1 = NHID > 1 && P.hidden[NHID > 1 ? 1 : 0] > 32;
-    float* const my_part = l_part + wave * MAXA * 64;
-
-    for (int t = 0; t < k_steps; ++t) {
-        // ---- what the policy sees of obs_t (k_rollout_fnn's input row, kept in registers)
-        float x[FNN_XS];
-        if (P.ident) {
-#pragma unroll
-            for (int k = 0; k < MAXO; ++k) x[k] = k < E::O ? ob[k] : 0.f;
-        } else {
-#pragma unroll
-            for (int k = 0; k < MAXO; ++k) {
-                float v = 0.f;
-#pragma unroll
-                for (int j = 0; j < E::O; ++j) v = (k < P.n_vis && P.obs_idx[k] == j) ? ob[j] : v;  // wave-uniform selects
-                x[k] = v;
-            }
-        }
-#pragma unroll
-        for (int k = MAXO; k < FNN_XS; ++k) x[k] = 0.f;
-        if (P.feat) {  // [o_0, sin o_1, cos o_1, o_2 ..]
-            float sn, cs;
-            sincos_fast(x[1], &sn, &cs);
-#pragma unroll
-            for (int k = MAXO; k >= 3; --k) x[k] = x[k - 1];
-            x[1] = sn, x[2] = cs;
-        }
-        // ---- the network of the wave's 32 envs
-        auto nonlin16 = [&](int kind, fnn_acc* v, bool wide) __attribute__((always_inline)) {  // kind, wide: wave-uniform
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                if (u == 1 && !wide) continue;
-                if (kind == FNN_TANH) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float xv = v[u][r];
-                        const float tt = __builtin_amdgcn_exp2f(-2.885390081777927f * fabsf(xv));
-                        v[u][r] = copysignf((1.0f - tt) * __builtin_amdgcn_rcpf(1.0f + tt), xv);
-                    }
-                } else if (kind != FNN_ID) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) v[u][r] = fnn_nonlin(kind, v[u][r]);
-                }
-            }
-        };
-        auto bias_init = [&](int l, fnn_acc* v) __attribute__((always_inline)) {
-#pragma unroll
-            for (int u = 0; u < 2; ++u)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const float4 b4 = *reinterpret_cast<const float4*>(l_bias + l * FNN_W + 32 * u + 8 * g + 4 * half);
-                    v[u][4 * g] = b4.x, v[u][4 * g + 1] = b4.y, v[u][4 * g + 2] = b4.z, v[u][4 * g + 3] = b4.w;
-                }
-        };
-        fnn_acc h1[2], h2[2];
-        bias_init(0, h1);
-#pragma unroll
-        for (int kk = 0; kk < FNN_XS / 2; ++kk) {
-            if (2 * kk >= P.in_dim) continue;  // (wave-uniform: the padding inputs)
-            const float xb = half ? x[2 * kk + 1] : x[2 * kk];
-            h1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[0][kk], xb, h1[0], 0, 0, 0);
-            if (wide0) h1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[1][kk], xb, h1[1], 0, 0, 0);
-        }
-        nonlin16(P.hid_nonlin[0], h1, wide0);
-        if constexpr (NHID > 1) {
-            bias_init(1, h2);
-#pragma unroll
-            for (int up = 0; up < 2; ++up) {
-                if (up == 1 && !wide0) continue;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float xb = h1[up][r];
-                    h2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[0][up][r], xb, h2[0], 0, 0, 0);
-                    if (wide1) h2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[1][up][r], xb, h2[1], 0, 0, 0);
-                }
-            }
-            nonlin16(P.hid_nonlin[1], h2, wide1);
-        }
-        fnn_acc* const hl = NHID > 1 ? h2 : h1;
-        const bool widel = NHID > 1 ? wide1 : wide0;
-#pragma unroll
-        for (int j = 0; j < E::A; ++j) {
-            float part = 0.f;
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                if (u == 1 && !widel) continue;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const float4 w4 = *reinterpret_cast<const float4*>(l_wo + j * FNN_W + 32 * u + 8 * g + 4 * half);
-                    part = fmaf(w4.x, hl[u][4 * g], part);
-                    part = fmaf(w4.y, hl[u][4 * g + 1], part);
-                    part = fmaf(w4.z, hl[u][4 * g + 2], part);
-                    part = fmaf(w4.w, hl[u][4 * g + 3], part);
-                }
-            }
-            // the other half-wave holds the other 32 units of the same env
-            my_part[j * 64 + lane] = part;
-            wave_lds_fence();
-            const float other = my_part[j * 64 + (lane ^ 32)];
-            a[j] = fnn_nonlin(P.out_nonlin, (part + other) + P.w[P.off_b[NHID] + j]);
-        }
-        if (P.noisy) {
-            uint4 b = Rng::philox(noise_seed, d.idx0 + (uint32_t)i, RNG_POLICY_NOISE, ((uint64_t)es.epi << 32) | (uint32_t)step);
-            float z[2];
-            Rng::box_muller(b.x, b.y, z[0], z[1]);
-#pragma unroll
-            for (int j = 0; j < E::A; ++j) a[j] = fmaf(P.noise_std[j], z[j], a[j]);
-        }
-        // ---- the env step: rollout_body's, statement for statement (both half-waves; the lower one writes)
-        float s_pre[E::S], h_pre[E::H > 0 ? E::H : 1], a_app[E::A], ow[E::O];
-#pragma unroll
-        for (int j = 0; j < E::O; ++j) ow[j] = ob[j];
-        if (REC == 2) {
-#pragma unroll
-            for (int j = 0; j < E::S; ++j) s_pre[j] = s[j];
-#pragma unroll
-            for (int j = 0; j < E::H; ++j) h_pre[j] = h[j];
-            applied_action<E>(T, c, alo, ahi, a, a_app);
-        }
-        if (!frozen) {
-            StepOut o = step_one<E, float>(T, c, s, h, a, step, yielded,
-                                           E::TRIG > 0 ? (const float*)(ob + E::TRIG_AT) : (const float*)nullptr);
-            rew = o.rew;
-            done = o.done;
-            failed = o.failed;
-            ret += o.rew;
-            if (o.err && valid) d.err[i] = 1;
-        } else {
-            rew = 0.f;
-        }
-        if (REC) {
-            if (writer) {
-                store_record<E, REC>(d.traj_rec + (rec0 + (size_t)t) * Rec<E, REC>::F * ld, ld, i, ow, a, rew, s_pre, a_app, h_pre);
-                db.put(d, i, rec0 + (size_t)t, done, t == k_steps - 1);
-            }
-        }
-        bool fin = done && valid && !frozen;
-        if (AR) {
-            auto_reset<E, UNI>(T, d, fin, i, reset_seed, c, s, h, step, ret, yielded, es, writer);
-            E::act_bounds(c, alo, ahi);
-        } else {
-            if (fin) {
-                es.count += 1u;
-                es.retsum += ret;
-                es.lensum += step;
-            }
-            if (d.log_episodes) append_episode(d, fin && writer, i, ret, step);
-            frozen |= done;
-        }
-        E::observe(s, ob);
-    }
-    if (!writer) return;
 #pragma unroll
     for (int j = 0; j < E::S; ++j) d.state[j * ld + i] = s[j];
 #pragma unroll
@@ -2536,21 +2282,9 @@ void Launch<E>::rollout_fnn(vs_env* h, int k, int rec, uint64_t noise_seed) {
     // 1: 256-env workgroups on the vector ALU, 2: 256-env workgroups on the matrix cores (7.8 us per step of up to 256 envs
     // per compute unit: the choice beyond 64 envs per compute unit; profiles/r02_table_policy_kernel.txt)
     int shape = (int64_t)h->d.ld > 64 * (int64_t)h->n_cu ? 2 : 0;
-    if (force) shape = force[0] == 'w' ? 3 : force[0] == 'm' ? 2 : force[0] == '2' ? 1 : 0;
+    if (force) shape = force[0] == 'm' ? 2 : force[0] == '2' ? 1 : 0;
     if (h->policy_shape >= 0) shape = h->policy_shape;
     if (h->fnn.n_hidden > 2) shape = 0;
-    if (shape == 3) {  // k_rollout_fnn_w: a wave owns 32 envs, no barrier in the step loop
-        static const char* sk = getenv("VS_FNN_SKEW");
-        const int skew = sk ? atoi(sk) : FNN_W_SKEW;
-#define LW(AR, REC, NH) hipLaunchKernelGGL((k_rollout_fnn_w<E, AR, REC, NH>), dim3((unsigned)(h->d.ld / 256)), dim3(512), 0, h->stream, h->task, h->d, h->fnn, k, h->ar_seed, noise_seed, skew)
-#define LWR(AR, NH) { if (rec == 0) LW(AR, 0, NH); else if (rec == 1) LW(AR, 1, NH); else LW(AR, 2, NH); }
-#define LWA(NH) { if (h->auto_reset) LWR(true, NH) else LWR(false, NH) }
-        if (h->fnn.n_hidden == 1) LWA(1) else LWA(2)
-#undef LWA
-#undef LWR
-#undef LW
-        return;
-    }
     switch (h->fnn.n_hidden) {
         case 1: if (shape == 2) LFA(1, 256, true) else if (shape == 1) LFA(1, 256, false) else LFA(1, 64, false) break;
         case 2: if (shape == 2) LFA(2, 256, true) else if (shape == 1) LFA(2, 256, false) else LFA(2, 64, false) break;

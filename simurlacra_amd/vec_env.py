@@ -410,7 +410,7 @@ class VecSimEnv:
         fused kernel (bit-identical results every way)"""
         self._check(self._lib.vs_set_rollout_variant(self._h, self._VARIANTS[variant]), "vs_set_rollout_variant")
 
-    _POLICY_SHAPES = {None: -1, "64": 0, "256": 1, "mfma": 2, "mfma_w": 3}
+    _POLICY_SHAPES = {None: -1, "64": 0, "256": 1, "mfma": 2}
 
     def set_policy_shape(self, shape=None):
         """None: automatic; '64' / '256': the in-kernel policy network on the vector ALU in 64- / 256-env workgroups; 'mfma': 256-env

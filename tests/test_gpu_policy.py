@@ -67,14 +67,13 @@ CASES = [  # family, hidden sizes, hidden nonlin, output nonlin, featurisation, 
 ]
 
 
-@pytest.mark.parametrize("shape", [None, "256", "mfma", "mfma_w"])
+@pytest.mark.parametrize("shape", [None, "256", "mfma"])
 @pytest.mark.parametrize("auto_reset", [False, True])
 @pytest.mark.parametrize("case", range(len(CASES)))
 def test_policy_kernel_against_torch_and_the_step_kernel(vs, case, auto_reset, shape):
     """shape: how k_rollout_fnn evaluates the network -- None: the automatic choice (here: 64-env workgroups, lane = hidden unit
     on the vector ALU), '256': the same in 256-env workgroups, 'mfma': the hidden layers on the matrix cores
-    (v_mfma_f32_32x32x2_f32, fp32; one and two hidden layers, tiles of a narrow layer skipped), 'mfma_w': k_rollout_fnn_w,
-    the same MFMAs with a wave owning 32 envs from observation to env step (no barrier in the step loop)"""
+    (v_mfma_f32_32x32x2_f32, fp32; one and two hidden layers, tiles of a narrow layer skipped)"""
     L = vs._lib
     name, hidden, nonlin, out_nonlin, feat, idx, gain = CASES[case]
     if shape is not None and len(hidden) > 2:
@@ -167,46 +166,6 @@ def test_policy_kernel_exploration_noise(vs):
     c.step_policy(T, record=True, noise_seed=78)
     assert not np.array_equal(c.traj(T)["act"], a["act"])  # another seed, another draw
     c.close()
-
-
-@pytest.mark.parametrize("name", ["qq-su", "qcp-su", "qbb", "bob"])
-def test_barrier_free_matrix_core_kernel_equals_the_workgroup_one(vs, name):
-    """k_rollout_fnn_w (a wave owns 32 envs, both half-waves carry them, the lower one writes) against k_rollout_fnn<MF>: same A
-    operands, same accumulation order, same half-wave sums -- every record plane, done bit, final buffer and the episode log
-    (as a set: the append order is the waves') bit for bit, with exploration noise, short episodes (auto-reset) and a ragged batch"""
-    n, T = 1000, 90
-    O, A = vs.env_dims(name)["O"], vs.env_dims(name)["A"]
-    kw = dict(KW[name], max_steps=23)
-    out = []
-    for shape in ("mfma", "mfma_w"):
-        net = make_net(vs, O, A, [64, 48], "tanh", None, 1.0, seed=5)
-        e = vs.VecSimEnv(name, n, **kw)
-        e.set_auto_reset(True, seed=4)
-        e.reset(seed=6)
-        e.set_policy_fnn(torch.nn.utils.parameters_to_vector(net.parameters()), [64, 48], "tanh", None,
-                         noise_std=np.full(A, 0.2, dtype=np.float32))
-        e.set_policy_shape(shape)
-        e.set_record_mode(2)
-        e.set_episode_log(True)
-        e.set_traj_capacity(T)
-        t = 0
-        for k in (1, 40, 49):
-            e.set_traj_offset(t)
-            e.step_policy(k, record=True, noise_seed=9)
-            t += k
-        tr = e.traj(T)
-        L = vs._lib
-        fin = {b: e.get(b) for b in (L.VS_STATE, L.VS_OBS, L.VS_RETURNS, L.VS_STEPCOUNT, L.VS_DONE, L.VS_EPSTAT_COUNT, L.VS_EPSTAT_RETSUM)}
-        log = e.episodes()
-        out.append((tr, fin, log))
-        e.close()
-    (ta, fa, la), (tb, fb, lb) = out
-    for key in ta:
-        assert np.array_equal(ta[key], tb[key], equal_nan=True), key
-    for key in fa:
-        assert np.array_equal(fa[key], fb[key], equal_nan=True), key
-    rows = lambda lg: sorted(zip(lg[2].tolist(), lg[1].tolist(), lg[0].tolist()))
-    assert len(la[0]) > n and rows(la) == rows(lb)
 
 
 def test_policy_kernel_argument_errors(vs):
