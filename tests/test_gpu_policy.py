@@ -64,6 +64,7 @@ CASES = [  # family, hidden sizes, hidden nonlin, output nonlin, featurisation, 
     ("omo", [16, 16, 16, 16], "tanh", None, False, None, 100.0),
     ("bob", [64], "tanh", None, True, None, 20.0),
     ("pend", [8, 64], "relu", None, False, [2, 0], 5.0),
+    ("qq-su", [32, 24], "tanh", None, False, None, 10.0),  # two narrow layers: the automatic choice is the matrix-core shape
 ]
 
 
@@ -72,7 +73,7 @@ CASES = [  # family, hidden sizes, hidden nonlin, output nonlin, featurisation, 
 @pytest.mark.parametrize("case", range(len(CASES)))
 def test_policy_kernel_against_torch_and_the_step_kernel(vs, case, auto_reset, shape):
     """shape: how k_rollout_fnn evaluates the network -- None: the automatic choice (here: 64-env workgroups, lane = hidden unit
-    on the vector ALU), '256': the same in 256-env workgroups, 'mfma': the hidden layers on the matrix cores
+    on the vector ALU; the matrix-core shape for two hidden layers of at most 32 units), '256': the same in 256-env workgroups, 'mfma': the hidden layers on the matrix cores
     (v_mfma_f32_32x32x2_f32, fp32; one and two hidden layers, tiles of a narrow layer skipped)"""
     L = vs._lib
     name, hidden, nonlin, out_nonlin, feat, idx, gain = CASES[case]
