@@ -62,3 +62,24 @@ for name, n in (("qq-su", 4096), ("qq-su", 16384), ("qq-su", 65536), ("qq-su", 2
         print(json.dumps(dict(kernel="k_rollout_fnn", env=name, envs=n, net="64x64 tanh + noise", record=rec, us_per_step=round(ms * 1e3 / 200, 3),
                               env_steps_per_s=round(n * 200 / (ms * 1e-3)))), flush=True)
     e.close()
+
+# the same rollouts as packed device tensors (sample_packed(): no host copy, no per-rollout objects)
+for name, kw, n in (("qq-su", dict(dt=0.004, max_steps=4000), 4096), ("qq-su", dict(dt=0.004, max_steps=4000), 65536)):
+    env = vs.ENV_CLASSES[name](**kw)
+    torch.manual_seed(0)
+    fnn = FNNPolicy(env.spec, [64, 64], torch.tanh, featurize=False)
+    for pol_name, pol in (("DummyPolicy (fused)", DummyPolicy(env.spec)), ("FNNPolicy 64x64 tanh, in the kernel (vs_step_policy)", fnn)):
+        s = ParallelRolloutSampler(env, pol, 8, min_rollouts=n, seed=0)
+        s.sample_packed(), s.sample_packed()
+        best = None
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            packs = s.sample_packed()
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            steps = sum(p.total_steps for p in packs)
+            if best is None or steps / el > best[0] / best[1]:
+                best = (steps, el)
+        print(json.dumps(dict(env=name, policy=pol_name, output="sample_packed(): device tensors", rollouts=n, env_steps=best[0],
+                              seconds=round(best[1], 4), env_steps_per_s=round(best[0] / best[1]))), flush=True)

@@ -28,7 +28,7 @@ inf = float("inf")
 
 def __getattr__(name):
     # torch-dependent pieces are imported on first use
-    if name in ("ParallelRolloutSampler", "StepSequence", "rollout", "CVaRSampler", "select_cvar"):
+    if name in ("ParallelRolloutSampler", "StepSequence", "PackedRollouts", "rollout", "CVaRSampler", "select_cvar"):
         from . import sampling
 
         return getattr(sampling, name)

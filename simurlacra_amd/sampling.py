@@ -116,6 +116,53 @@ class StepSequence:
         return f"StepSequence(len={self.length}, return={self.undiscounted_return():.4g})"
 
 
+class PackedRollouts:
+    """The rollouts of one batch of lanes as packed DEVICE tensors -- what `ParallelRolloutSampler.sample()` holds right before it
+    copies to the host and cuts `StepSequence`s, handed out as it is (`sample_packed()`): nothing crosses PCIe and no per-rollout
+    Python object is made.  For algorithm code that consumes rollouts on the GPU (the concatenated form the reference's
+    algorithms build with `StepSequence.concat`, P/sampling/step_sequence.py:777-825 -- which drops every rollout's final observation
+    and state (truncate_last); here they are kept).
+
+    Rollout j (j = 0 .. n - 1, in rollout order) owns steps `offsets[j] : offsets[j + 1]` of the per-step tensors and entries
+    `offsets[j] + j : offsets[j + 1] + j + 1` of the tensors with one entry more than steps (observations, states, th_ddot):
+
+      observations [total + n, O]   actions [total, A]   rewards [total] (float32)
+      states [total + n, S] | None  actions_applied [total, A] | None   th_ddot [total + n] | None  (full records)
+      lengths [n] (int64)   offsets [n + 1] (int64)   done_last [n] (bool: the rollout ended by done, not by the step limit)
+      init_states [n, S]    first_index: rollout number of rollout 0 within the sample() call
+    """
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+    def __len__(self):
+        return int(self.lengths.shape[0])
+
+    @property
+    def total_steps(self) -> int:
+        return int(self.actions.shape[0])
+
+    def step_slice(self, j: int) -> slice:
+        return slice(int(self.offsets[j]), int(self.offsets[j + 1]))
+
+    def obs_slice(self, j: int) -> slice:
+        return slice(int(self.offsets[j]) + j, int(self.offsets[j + 1]) + j + 1)
+
+    def rollout_index(self):
+        """[total] int64: the rollout every packed step belongs to"""
+        import torch
+
+        return torch.repeat_interleave(torch.arange(len(self), device=self.lengths.device), self.lengths,
+                                       output_size=self.total_steps)
+
+    def undiscounted_returns(self):
+        """[n] float32 on the device"""
+        import torch
+
+        out = torch.zeros(len(self), device=self.rewards.device, dtype=self.rewards.dtype)
+        return out.index_add_(0, self.rollout_index(), self.rewards)
+
+
 def rollout(env, policy, eval: bool = False, max_steps: Optional[int] = None, reset_kwargs: Optional[dict] = None,
             render_mode=None, render_step: int = 1, no_reset: bool = False, no_close: bool = False,
             record_dts: bool = False, stop_on_done: bool = True, seed: Optional[int] = None,
@@ -281,8 +328,8 @@ class ParallelRolloutSampler:
         self._fc = fuse_wrappers(self.env)  # ActNorm / act noise / act delay / obs norm / obs noise / partial obs
         return v
 
-    def _run_batch(self, work, first_index, eval):
-        """run len(work) rollouts as lanes; returns List[StepSequence] in order"""
+    def _run_batch(self, work, first_index, eval, packed_out=False):
+        """run len(work) rollouts as lanes; returns List[StepSequence] in order (packed_out: one PackedRollouts)"""
         import torch
 
         n = len(work)
@@ -291,11 +338,11 @@ class ParallelRolloutSampler:
         # current stream for the duration of the batch (pointer 0 = the legacy default stream)
         v.use_stream(torch.cuda.current_stream(v.device).cuda_stream)
         try:
-            return self._run_batch_on_stream(v, work, first_index, eval)
+            return self._run_batch_on_stream(v, work, first_index, eval, packed_out)
         finally:
             v.use_stream(None)
 
-    def _run_batch_on_stream(self, v, work, first_index, eval):
+    def _run_batch_on_stream(self, v, work, first_index, eval, packed_out=False):
         import torch
 
         n = len(work)
@@ -492,6 +539,14 @@ class ParallelRolloutSampler:
                 hid_all[k_idx + lane] = hid_s
                 hid_all[start + length + ar] = fin_h
                 more.append(hid_all)
+        if packed_out:
+            qcp_dev = base.name.startswith("qcp") and H and extra is not None
+            return PackedRollouts(
+                observations=obs_all, actions=act_s.contiguous(), rewards=rew_s.contiguous(),
+                states=more[0] if more else None, actions_applied=more[1] if more else None,
+                th_ddot=more[2][:, 0] if qcp_dev else None, lengths=length, offsets=torch.cat([start, start[-1:] + length[-1:]]),
+                done_last=done_T[first, ar].bool(), init_states=state0.contiguous(), first_index=first_index,
+                env_name=base.name, dt=base.dt, param_names=v.param_names, domain_params=v.tensor(L.VS_PARAMS)[:, :n].t().clone())
         # device -> host through pinned staging buffers (a pageable .cpu() of ~70 MB runs at ~3 GB/s here), then one memcpy
         # each into arrays the caller owns
         host = self._to_host(
@@ -588,6 +643,19 @@ class ParallelRolloutSampler:
                     return out
             idx += nb
             guess = max(guess, int(len(out) * (self.min_steps / max(steps, 1) - 1)) + 1)
+
+
+    def sample_packed(self, init_states: Optional[List[np.ndarray]] = None, domain_params: Optional[List[dict]] = None,
+                      eval: bool = False) -> List[PackedRollouts]:
+        """sample() without the host side: the same rollouts (same work list, seeds and order) as packed device tensors, one
+        `PackedRollouts` per batch of lanes (one in all but very large calls).  No counterpart in the reference, whose workers
+        return host `StepSequence`s; `min_rollouts` mode only."""
+        if self.min_steps is not None:
+            raise ValueErr(msg="sample_packed() runs a fixed number of rollouts: construct the sampler with min_rollouts")
+        self._sample_count += 1
+        work = self.work_list(init_states, domain_params)
+        return [self._run_batch(work[a:a + self._batch_lanes], a, eval, packed_out=True)
+                for a in range(0, len(work), self._batch_lanes)]
 
 
 def select_cvar(rollouts: list, epsilon: float, gamma: float = 1.0) -> list:
