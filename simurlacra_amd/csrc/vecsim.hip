@@ -864,6 +864,20 @@ int vs_step_policy(vs_handle h, int k_steps, int record, uint64_t noise_seed) {
     return VS_OK;
 }
 
+int vs_pack_traj(vs_handle h, int n_lanes, int t_steps, const int64_t* lengths, const int64_t* starts, float* obs_all, float* act,
+                 float* rew, float* state_all, float* act_app, float* hidden_all) {
+    if (!h || n_lanes < 1 || n_lanes > h->d.n || t_steps < 1 || !lengths || !starts || !obs_all || !act || !rew)
+        return fail(h, VS_ERR_ARG, "vs_pack_traj: bad argument");
+    if (!h->d.traj_rec || t_steps > h->traj_cap) return fail(h, VS_ERR_STATE, "vs_pack_traj: more steps than vs_set_traj_capacity holds");
+    if (h->record_mode == 2 && (!state_all || !act_app || (ENV_INFO[h->type].H > 0 && !hidden_all)))
+        return fail(h, VS_ERR_ARG, "vs_pack_traj: record mode 2 needs the state / applied-action / hidden destinations");
+    HIPCHK(h, hipSetDevice(h->device));
+    DISPATCH_ENV(h->type, Launch<E>::pack_traj(h, n_lanes, t_steps, (const long long*)lengths, (const long long*)starts, obs_all, act,
+                                               rew, state_all, act_app, hidden_all));
+    HIPCHK(h, hipGetLastError());
+    return VS_OK;
+}
+
 int vs_set_episode_log(vs_handle h, int on) {
     if (!h) return VS_ERR_ARG;
     h->d.log_episodes = on != 0;

@@ -1989,6 +1989,75 @@ __global__ __launch_bounds__(BLOCK) void k_step_mixed(const Segs* __restrict__ s
 }
 #endif  // VS_TU_MIXED
 
+// ------------------------------------------------------------------------------------------ rollouts out of the records
+// vs_pack_traj: the recorded steps of the first n lanes, time-major planes [t][plane][lane], into rollout-major arrays -- rollout
+// j = steps 0 .. len[j] - 1 of lane j, the rollouts one after the other (what rollout() returns per env, rollout.py:305-325, and
+// StepSequence.concat makes of many, step_sequence.py:777-825): per-step arrays (act, rew, act_app) at row start[j] + t, the
+// arrays with one entry more than steps (obs, state, hidden: the value before every step and the final one, read from
+// VS_OBS / VS_STATE / VS_HIDDEN of the frozen lane) at row start[j] + j + t.
+// A thread streams ONE lane over a chunk of `tchunk` steps: for a given t the 64 lanes of a wave read 64 x 16 contiguous bytes
+// per record plane; a lane's stores walk through its own rows (24 + 4 + 4 + 16 + 4 B per step for QQube, full records), which
+// the L2 merges into whole lines before they leave.  HBM-bound: (F read + F written) x 4 B per recorded step.
+template <int N>
+__device__ __forceinline__ void store_row(float* __restrict__ dst, const float* v) {  // dst = base + row * N: N * 4-B aligned
+    if constexpr (N % 4 == 0) {
+#pragma unroll
+        for (int q = 0; q < N / 4; ++q) reinterpret_cast<float4*>(dst)[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+    } else if constexpr (N % 2 == 0) {
+#pragma unroll
+        for (int q = 0; q < N / 2; ++q) reinterpret_cast<float2*>(dst)[q] = make_float2(v[2 * q], v[2 * q + 1]);
+    } else {
+#pragma unroll
+        for (int q = 0; q < N; ++q) dst[q] = v[q];
+    }
+}
+
+template <class E, int REC>
+__global__ __launch_bounds__(BLOCK) void k_pack_traj(Dev d, int n, int tchunk, const long long* __restrict__ len,
+                                                     const long long* __restrict__ start, float* __restrict__ obs_all,
+                                                     float* __restrict__ act, float* __restrict__ rew,
+                                                     float* __restrict__ st_all, float* __restrict__ app,
+                                                     float* __restrict__ hid_all) {
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    constexpr int F = Rec<E, REC>::F;
+    constexpr int B = E::O + E::A + 1;
+    const size_t ld = d.ld;
+    const long long L = len[i], s0 = start[i];
+    const long long t0 = (long long)blockIdx.y * tchunk;
+    const long long t1 = t0 + tchunk < L ? t0 + tchunk : L;
+#pragma unroll 2
+    for (long long t = t0; t < t1; ++t) {
+        float v[F];
+        Planes<F>::load(d.traj_rec + (size_t)t * F * ld, ld, i, v);
+        const size_t k = (size_t)(s0 + t), ko = k + (size_t)i;
+        store_row<E::O>(obs_all + ko * E::O, v);
+        store_row<E::A>(act + k * E::A, v + E::O);
+        rew[k] = v[E::O + E::A];
+        if constexpr (REC == 2) {
+            store_row<E::S>(st_all + ko * E::S, v + B);
+            store_row<E::A>(app + k * E::A, v + B + E::S);
+            if constexpr (E::H > 0) store_row<E::H>(hid_all + ko * E::H, v + B + E::S + E::A);
+        }
+        if (t == L - 1) {  // the entry behind the rollout's last step: the frozen lane's final observation / state
+            float fo[E::O], fs[E::S], fh[E::H > 0 ? E::H : 1];
+#pragma unroll
+            for (int j = 0; j < E::O; ++j) fo[j] = d.obs[j * ld + i];
+            store_row<E::O>(obs_all + (ko + 1) * E::O, fo);
+            if constexpr (REC == 2) {
+#pragma unroll
+                for (int j = 0; j < E::S; ++j) fs[j] = d.state[j * ld + i];
+                store_row<E::S>(st_all + (ko + 1) * E::S, fs);
+                if constexpr (E::H > 0) {
+#pragma unroll
+                    for (int j = 0; j < E::H; ++j) fh[j] = d.hidden[j * ld + i];
+                    store_row<E::H>(hid_all + (ko + 1) * E::H, fh);
+                }
+            }
+        }
+    }
+}
+
 // -------------------------------------------------------------------------------------------- params / reset kernels
 // domain_param setter (P/environments/pysim/base.py:112-124): _calc_constants + spaces + task.reset for masked lanes.
 // src == nullptr: recompute from the stored params; bcast: src is one [P] vector for every lane.
@@ -2144,6 +2213,8 @@ struct Launch {
     static void sample_params(vs_env* h, uint64_t seed, const uint8_t* mask);
     static void reset(vs_env* h, const float* init, long pitch, int full, const uint8_t* mask, uint64_t seed);
     static void observe(vs_env* h);
+    static void pack_traj(vs_env* h, int n, int t_steps, const long long* len, const long long* start, float* obs_all, float* act,
+                          float* rew, float* st_all, float* app, float* hid_all);  // vs_pack_traj
 };
 
 // mixed batches: defined in vecsim_mixed.hip
@@ -2325,6 +2396,18 @@ void Launch<E>::reset(vs_env* h, const float* init, long pitch, int full, const 
 template <class E>
 void Launch<E>::observe(vs_env* h) {
     hipLaunchKernelGGL(k_observe<E>, grid_for(h->d.ld), dim3(BLOCK), 0, h->stream, h->d);
+}
+
+template <class E>
+void Launch<E>::pack_traj(vs_env* h, int n, int t_steps, const long long* len, const long long* start, float* obs_all, float* act,
+                          float* rew, float* st_all, float* app, float* hid_all) {
+    // chunks of 64 steps per thread: 65 536 lanes x 4 000 steps = 16 128 workgroups, 4 096 lanes still 1 008
+    const int tchunk = 64;
+    dim3 g((unsigned)((n + BLOCK - 1) / BLOCK), (unsigned)((t_steps + tchunk - 1) / tchunk));
+    if (h->record_mode == 2)
+        hipLaunchKernelGGL((k_pack_traj<E, 2>), g, dim3(BLOCK), 0, h->stream, h->d, n, tchunk, len, start, obs_all, act, rew, st_all, app, hid_all);
+    else
+        hipLaunchKernelGGL((k_pack_traj<E, 1>), g, dim3(BLOCK), 0, h->stream, h->d, n, tchunk, len, start, obs_all, act, rew, st_all, app, hid_all);
 }
 #endif  // VS_TU_FAMILY
 

@@ -424,20 +424,6 @@ class ParallelRolloutSampler:
                 if bool(done_t.bool().all()):  # one scalar sync per launch
                     break
             v.set_traj_offset(0)
-            fields = v.record_fields()
-            done_T = v.traj_done(t, n)  # [T, n]
-
-            def gather(ti, li):  # only the steps that belong to a rollout are ever read from the record planes
-                rec = v.gather_traj(ti, li)
-                col = lambda k: rec[:, fields[k][0]:fields[k][0] + fields[k][1]]
-                extra = (col("state"), col("act_app"), col("hidden")) if full else None
-                return visible(col("obs"), 1), col("act"), rec[:, fields["rew"][0]], extra
-
-            def final_obs(length, T):  # lanes freeze at done: VS_OBS is the observation after every lane's last step
-                return visible(obs_full, 0).t()
-
-            def final_state(length, T):  # ... and VS_STATE / VS_HIDDEN the state it belongs to
-                return st_t.t(), (hid_t.t() if H else None)
         elif fnn is not None:
             # rollout() with a network policy == vs_step_policy: observation -> network -> (exploration noise) -> step ->
             # record inside ONE kernel, `chunk` steps per launch, lanes freeze at done; the same record planes as above
@@ -456,20 +442,6 @@ class ParallelRolloutSampler:
                 if bool(done_t.bool().all()):  # one scalar sync per launch
                     break
             v.set_traj_offset(0)
-            fields = v.record_fields()
-            done_T = v.traj_done(t, n)  # [T, n]
-
-            def gather(ti, li):
-                rec = v.gather_traj(ti, li)
-                col = lambda k: rec[:, fields[k][0]:fields[k][0] + fields[k][1]]
-                extra = (col("state"), col("act_app"), col("hidden")) if full else None
-                return visible(col("obs"), 1), col("act"), rec[:, fields["rew"][0]], extra
-
-            def final_obs(length, T):
-                return visible(obs_full, 0).t()
-
-            def final_state(length, T):
-                return st_t.t(), (hid_t.t() if H else None)
         else:
             # policy in the loop: rollout() with the caller's policy (rollout.py:185-258).  One recording step kernel per env
             # step -- vs_step_record writes the observation the policy saw, its action, the reward, the done bit and (full
@@ -495,52 +467,25 @@ class ParallelRolloutSampler:
                     if (t % 32 == 0 or t == T_cap) and bool(done_t.bool().all()):  # one scalar sync per 32 steps
                         break
             v.set_freeze_done(False)
-            fields = v.record_fields()
-            done_T = v.traj_done(t, n)  # [T, n]
-
-            def gather(ti, li):
-                rec = v.gather_traj(ti, li)
-                col = lambda k: rec[:, fields[k][0]:fields[k][0] + fields[k][1]]
-                extra = (col("state"), col("act_app"), col("hidden")) if full else None
-                return visible(col("obs"), 1), col("act"), rec[:, fields["rew"][0]], extra
-
-            def final_obs(length, T):  # finished lanes are frozen: VS_OBS is the observation after every lane's last step
-                return visible(obs_full, 0).t()
-
-            def final_state(length, T):
-                return st_t.t(), (hid_t.t() if H else None)
         v.raise_on_error()
-        # ---- split into rollouts on the device: rollout j = steps 0 .. first done of lane j, packed lane-major ----
+        # ---- split into rollouts on the device: rollout j = steps 0 .. first done of lane j, packed lane-major.  Lanes freeze
+        # at done (all three paths): VS_OBS / VS_STATE / VS_HIDDEN hold every lane's final observation and state.  One kernel
+        # (vs_pack_traj) reads only the steps that belong to a rollout from the record planes and writes the packed arrays.
         T = t
+        done_T = v.traj_done(T, n)  # [T, n]
         ar = torch.arange(n, device=dev)
         any_done = done_T.any(dim=0)
         first = torch.where(any_done, done_T.to(torch.uint8).argmax(dim=0), torch.full_like(ar, T - 1))
         length = first + 1  # [n]
         total = int(length.sum())  # the one size-dependent sync
-        lane = torch.repeat_interleave(ar, length, output_size=total)  # packed step k belongs to lane[k] ...
         start = torch.cumsum(length, 0) - length
-        k_idx = torch.arange(total, device=dev)
-        t_idx = k_idx - start[lane]  # ... at time t_idx[k]
-        obs_s, act_s, rew_s, extra = gather(t_idx, lane)
-        obs_all = torch.empty(total + n, obs_s.shape[1], device=dev)  # one observation more than steps per rollout
-        obs_all[k_idx + lane] = obs_s
-        obs_all[start + length + ar] = final_obs(length, T)
-        more = []
-        if extra is not None:
-            # states [T + 1, S] and (qcp) th_ddot [T + 1]: the value before every step and the final one, like observations
-            st_s, app_s, hid_s = extra
-            fin_s, fin_h = final_state(length, T)
-            st_all = torch.empty(total + n, S, device=dev)
-            st_all[k_idx + lane] = st_s
-            st_all[start + length + ar] = fin_s
-            more = [st_all, app_s.contiguous()]
-            if H:
-                hid_all = torch.empty(total + n, H, device=dev)
-                hid_all[k_idx + lane] = hid_s
-                hid_all[start + length + ar] = fin_h
-                more.append(hid_all)
+        pk = v.pack_traj(n, T, length, start, total=total)
+        obs_all = visible(pk["obs"], 1)  # [total + n, O']: one observation more than steps per rollout
+        act_s, rew_s = pk["act"], pk["rew"]
+        # states [T + 1, S] and (qcp) th_ddot [T + 1]: the value before every step and the final one, like observations
+        more = ([pk["state"], pk["act_app"]] + ([pk["hidden"]] if H else [])) if full else []
         if packed_out:
-            qcp_dev = base.name.startswith("qcp") and H and extra is not None
+            qcp_dev = base.name.startswith("qcp") and H and bool(more)
             return PackedRollouts(
                 observations=obs_all, actions=act_s.contiguous(), rewards=rew_s.contiguous(),
                 states=more[0] if more else None, actions_applied=more[1] if more else None,

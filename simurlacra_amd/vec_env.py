@@ -475,6 +475,27 @@ class VecSimEnv:
         planes, _ = self.traj_planes()
         return torch.cat([p[t_idx, lane_idx] for p, _ in planes], dim=1)
 
+    def pack_traj(self, n, t_steps, lengths, starts, total=None):
+        """vs_pack_traj: rollout j = the first lengths[j] recorded steps of lane j (j < n), packed one after the other on the
+        device (lengths / starts: int64 device tensors, starts the exclusive cumulative sum).  Returns dict(obs [total + n, O],
+        act [total, A], rew [total]; record mode 2: state [total + n, S], act_app [total, A], hidden [total + n, H] | None)"""
+        import torch
+
+        total = int(starts[-1] + lengths[-1]) if total is None else int(total)  # (a device sync unless the caller knows it)
+        dev = lengths.device
+        O, A, S, H = self.dims["O"], self.dims["A"], self.dims["S"], self.dims["H"]
+        full = self.record_mode == 2
+        out = dict(obs=torch.empty(total + n, O, device=dev), act=torch.empty(total, A, device=dev), rew=torch.empty(total, device=dev))
+        if full:
+            out.update(state=torch.empty(total + n, S, device=dev), act_app=torch.empty(total, A, device=dev),
+                       hidden=torch.empty(total + n, H, device=dev) if H else None)
+        ptr = lambda k: C.c_void_p(out[k].data_ptr()) if out.get(k) is not None else None
+        lengths, starts = lengths.to(torch.int64).contiguous(), starts.to(torch.int64).contiguous()
+        self._check(self._lib.vs_pack_traj(self._h, int(n), int(t_steps), C.c_void_p(lengths.data_ptr()), C.c_void_p(starts.data_ptr()),
+                                           ptr("obs"), ptr("act"), ptr("rew"), ptr("state"), ptr("act_app"), ptr("hidden")),
+                    "vs_pack_traj")
+        return out
+
     def traj_tensors(self, k_steps=None, n=None):
         """The recorded steps as torch tensors on the device: dict(obs [T, n, O], act [T, n, A], rew [T, n], done [T, n] u8;
         in record mode 2 also state [T, n, S], act_app [T, n, A], hidden [T, n, H]).  `rec` ([T, n, F], one gather of the

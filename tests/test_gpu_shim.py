@@ -606,3 +606,52 @@ def test_sample_packed_holds_what_sample_returns(vs, name, policy_kind):
         j0 += len(p)
     with pytest.raises(vs.ValueErr):
         ParallelRolloutSampler(env, pol, 2, min_steps=100, seed=11).sample_packed()
+
+
+@pytest.mark.parametrize("name", ["omo", "bob", "qq-su", "qcp-su", "qbb", "pend"])
+@pytest.mark.parametrize("mode", [1, 2])
+def test_pack_traj_kernel_equals_the_index_gather(vs, name, mode):
+    """vs_pack_traj (time-major record planes -> rollout-major packed arrays, one kernel) against torch index arithmetic on
+    traj_tensors(): ragged batch (n = 300 of ld = 512), lengths from the first done (or the launch's end) and shorter, both record modes,
+    rollouts longer than one 64-step chunk of the kernel; final entries = VS_OBS / VS_STATE / VS_HIDDEN of the frozen lanes"""
+    import torch
+
+    L = vs._lib
+    n, T = 300, 150
+    e = vs.VecSimEnv(name, n, **dict(KW[name], max_steps=110))
+    e.set_auto_reset(False)
+    e.reset(seed=5)
+    e.set_record_mode(mode)
+    e.set_traj_capacity(T)
+    for t0, k in ((0, 70), (70, 80)):
+        e.set_traj_offset(t0)
+        e.step_random(k, seed=9, record=True)
+    e.set_traj_offset(0)
+    e.sync()
+    tt = e.traj_tensors(T, n)
+    done = tt["done"].bool()  # [T, n]
+    ar = torch.arange(n, device=done.device)
+    first = torch.where(done.any(0), done.to(torch.uint8).argmax(0), torch.full_like(ar, T - 1))
+    length = torch.minimum(first + 1, 1 + (ar * 37) % T)  # (cut further, lane by lane: the kernel moves what the lengths say)
+    start = torch.cumsum(length, 0) - length
+    assert int(length.min()) == 1 and int(length.max()) > 64  # one-step and multi-chunk rollouts in one batch
+    pk = e.pack_traj(n, T, length, start)
+    torch.cuda.synchronize()
+    total = int(length.sum())
+    lane = torch.repeat_interleave(ar, length)
+    t_idx = torch.arange(total, device=lane.device) - start[lane]
+    fin = {"obs": e.tensor(L.VS_OBS)[:, :n].t(), "state": e.tensor(L.VS_STATE)[:, :n].t(),
+           "hidden": e.tensor(L.VS_HIDDEN)[:, :n].t() if e.dims["H"] else None}
+    for key in ("act", "rew") + (("act_app",) if mode == 2 else ()):
+        assert torch.equal(pk[key], tt[key][t_idx, lane]), key
+    for key in ("obs",) + (("state", "hidden") if mode == 2 else ()):
+        if key == "hidden" and not e.dims["H"]:
+            assert pk[key] is None
+            continue
+        want = torch.empty(total + n, tt[key].shape[2], device=lane.device)
+        want[torch.arange(total, device=lane.device) + lane] = tt[key][t_idx, lane]
+        want[start + length + ar] = fin[key]
+        assert torch.equal(pk[key], want), key
+    if mode == 1:
+        assert "state" not in pk
+    e.close()
