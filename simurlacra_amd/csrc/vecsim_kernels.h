@@ -1995,65 +1995,94 @@ __global__ __launch_bounds__(BLOCK) void k_step_mixed(const Segs* __restrict__ s
 // StepSequence.concat makes of many, step_sequence.py:777-825): per-step arrays (act, rew, act_app) at row start[j] + t, the
 // arrays with one entry more than steps (obs, state, hidden: the value before every step and the final one, read from
 // VS_OBS / VS_STATE / VS_HIDDEN of the frozen lane) at row start[j] + j + t.
-// A thread streams ONE lane over a chunk of `tchunk` steps: for a given t the 64 lanes of a wave read 64 x 16 contiguous bytes
-// per record plane; a lane's stores walk through its own rows (24 + 4 + 4 + 16 + 4 B per step for QQube, full records), which
-// the L2 merges into whole lines before they leave.  HBM-bound: (F read + F written) x 4 B per recorded step.
-template <int N>
-__device__ __forceinline__ void store_row(float* __restrict__ dst, const float* v) {  // dst = base + row * N: N * 4-B aligned
-    if constexpr (N % 4 == 0) {
-#pragma unroll
-        for (int q = 0; q < N / 4; ++q) reinterpret_cast<float4*>(dst)[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
-    } else if constexpr (N % 2 == 0) {
-#pragma unroll
-        for (int q = 0; q < N / 2; ++q) reinterpret_cast<float2*>(dst)[q] = make_float2(v[2 * q], v[2 * q + 1]);
-    } else {
-#pragma unroll
-        for (int q = 0; q < N; ++q) dst[q] = v[q];
-    }
-}
-
+// A transpose through LDS: a workgroup owns 64 lanes and walks through a segment of PK_SEG steps in tiles of TT steps.  Load
+// side: for a given step the 64 lanes read 64 x 16 contiguous bytes per record plane (only lanes whose rollout reaches that
+// step).  Store side: in every destination a lane's TT steps are one contiguous run (obs of QQube: 16 x 24 B), and consecutive
+// threads write consecutive floats of it -- whole 256-B pieces per wave instruction instead of 64 scattered rows (the first
+// version of this kernel had a thread stream one lane, 4- to 24-B stores into 64 different lines per instruction: 1.3 TB/s);
+// runs that end inside a line are completed by the same workgroup's next tile.  HBM-bound: (F read + F written) x 4 B per step.
+constexpr int PK_LANES = 64, PK_SEG = 256;
 template <class E, int REC>
-__global__ __launch_bounds__(BLOCK) void k_pack_traj(Dev d, int n, int tchunk, const long long* __restrict__ len,
+__global__ __launch_bounds__(BLOCK) void k_pack_traj(Dev d, int n, const long long* __restrict__ len,
                                                      const long long* __restrict__ start, float* __restrict__ obs_all,
                                                      float* __restrict__ act, float* __restrict__ rew,
                                                      float* __restrict__ st_all, float* __restrict__ app,
                                                      float* __restrict__ hid_all) {
-    const int i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i >= n) return;
     constexpr int F = Rec<E, REC>::F;
     constexpr int B = E::O + E::A + 1;
+    constexpr int TT = F > 16 ? 8 : 16;   // steps per tile: 64 x TT x F floats of LDS (QQube, full records: 53 KB)
+    constexpr int RS = TT * F + 1;        // odd row stride: the load side writes a column across 64 rows without bank conflicts
+    static_assert(BLOCK == 256 && PK_SEG % TT == 0, "four waves per workgroup");
+    __shared__ float tile[PK_LANES * RS];
+    __shared__ long long l_row[PK_LANES];  // start[lane] of the workgroup's lanes
+    __shared__ int l_len[PK_LANES];        // their rollout lengths (0 for lanes beyond n)
+    __shared__ int l_max;
+    const int lane0 = blockIdx.x * PK_LANES;
+    const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63;
     const size_t ld = d.ld;
-    const long long L = len[i], s0 = start[i];
-    const long long t0 = (long long)blockIdx.y * tchunk;
-    const long long t1 = t0 + tchunk < L ? t0 + tchunk : L;
-#pragma unroll 2
-    for (long long t = t0; t < t1; ++t) {
-        float v[F];
-        Planes<F>::load(d.traj_rec + (size_t)t * F * ld, ld, i, v);
-        const size_t k = (size_t)(s0 + t), ko = k + (size_t)i;
-        store_row<E::O>(obs_all + ko * E::O, v);
-        store_row<E::A>(act + k * E::A, v + E::O);
-        rew[k] = v[E::O + E::A];
-        if constexpr (REC == 2) {
-            store_row<E::S>(st_all + ko * E::S, v + B);
-            store_row<E::A>(app + k * E::A, v + B + E::S);
-            if constexpr (E::H > 0) store_row<E::H>(hid_all + ko * E::H, v + B + E::S + E::A);
-        }
-        if (t == L - 1) {  // the entry behind the rollout's last step: the frozen lane's final observation / state
-            float fo[E::O], fs[E::S], fh[E::H > 0 ? E::H : 1];
-#pragma unroll
-            for (int j = 0; j < E::O; ++j) fo[j] = d.obs[j * ld + i];
-            store_row<E::O>(obs_all + (ko + 1) * E::O, fo);
-            if constexpr (REC == 2) {
-#pragma unroll
-                for (int j = 0; j < E::S; ++j) fs[j] = d.state[j * ld + i];
-                store_row<E::S>(st_all + (ko + 1) * E::S, fs);
-                if constexpr (E::H > 0) {
-#pragma unroll
-                    for (int j = 0; j < E::H; ++j) fh[j] = d.hidden[j * ld + i];
-                    store_row<E::H>(hid_all + (ko + 1) * E::H, fh);
+    if (tid == 0) l_max = 0;
+    __syncthreads();
+    if (tid < PK_LANES) {
+        const int i = lane0 + tid;
+        const int L = i < n ? (int)len[i] : 0;
+        l_len[tid] = L;
+        l_row[tid] = i < n ? start[i] : 0;
+        atomicMax(&l_max, L);
+    }
+    __syncthreads();
+    const int seg0 = blockIdx.y * PK_SEG;
+    const int seg1 = min(seg0 + PK_SEG, l_max);
+    const int i = lane0 + l;
+    const int myL = l_len[l];
+    // the store side of one destination: W floats per step from column c0 of the record, rows `extra` = 1 for the arrays with
+    // one entry more than steps per rollout (their row index carries the rollout number as well)
+    auto put = [&](float* __restrict__ dst, auto wc, auto c0c, int extra, int tb) __attribute__((always_inline)) {
+        constexpr int W = decltype(wc)::value, C0 = decltype(c0c)::value;
+        if constexpr (W > 0) {
+            for (int e = tid; e < PK_LANES * TT * W; e += BLOCK) {
+                const int ln = e / (TT * W), r = e - ln * (TT * W);
+                const int ts = r / W, f = r - ts * W;
+                if (tb + ts < l_len[ln]) {
+                    const size_t row = (size_t)(l_row[ln] + tb + ts) + (extra ? (size_t)(lane0 + ln) : 0);
+                    dst[row * W + f] = tile[ln * RS + ts * F + C0 + f];
                 }
             }
+        }
+    };
+    for (int tb = seg0; tb < seg1; tb += TT) {
+        // ---- load side: wave w takes steps tb + w * (TT / 4) .. of the tile, a lane its own record
+#pragma unroll
+        for (int r = 0; r < TT / 4; ++r) {
+            const int ts = wave * (TT / 4) + r, t = tb + ts;
+            if (t < myL) {
+                float v[F];
+                Planes<F>::load(d.traj_rec + (size_t)t * F * ld, ld, i, v);
+#pragma unroll
+                for (int f = 0; f < F; ++f) tile[l * RS + ts * F + f] = v[f];
+            }
+        }
+        __syncthreads();
+        // ---- store side
+        put(obs_all, std::integral_constant<int, E::O>{}, std::integral_constant<int, 0>{}, 1, tb);
+        put(act, std::integral_constant<int, E::A>{}, std::integral_constant<int, E::O>{}, 0, tb);
+        put(rew, std::integral_constant<int, 1>{}, std::integral_constant<int, E::O + E::A>{}, 0, tb);
+        if constexpr (REC == 2) {
+            put(st_all, std::integral_constant<int, E::S>{}, std::integral_constant<int, B>{}, 1, tb);
+            put(app, std::integral_constant<int, E::A>{}, std::integral_constant<int, B + E::S>{}, 0, tb);
+            put(hid_all, std::integral_constant<int, E::H>{}, std::integral_constant<int, B + E::S + E::A>{}, 1, tb);
+        }
+        __syncthreads();
+    }
+    // ---- the entry behind a rollout's last step: the frozen lane's final observation / state (by the segment that holds it)
+    if (wave == 0 && myL > 0 && myL - 1 >= seg0 && myL - 1 < seg0 + PK_SEG) {
+        const size_t ko = (size_t)(l_row[l] + myL) + (size_t)i;
+#pragma unroll
+        for (int j = 0; j < E::O; ++j) obs_all[ko * E::O + j] = d.obs[j * ld + i];
+        if constexpr (REC == 2) {
+#pragma unroll
+            for (int j = 0; j < E::S; ++j) st_all[ko * E::S + j] = d.state[j * ld + i];
+#pragma unroll
+            for (int j = 0; j < E::H; ++j) hid_all[ko * E::H + j] = d.hidden[j * ld + i];
         }
     }
 }
@@ -2401,13 +2430,12 @@ void Launch<E>::observe(vs_env* h) {
 template <class E>
 void Launch<E>::pack_traj(vs_env* h, int n, int t_steps, const long long* len, const long long* start, float* obs_all, float* act,
                           float* rew, float* st_all, float* app, float* hid_all) {
-    // chunks of 64 steps per thread: 65 536 lanes x 4 000 steps = 16 128 workgroups, 4 096 lanes still 1 008
-    const int tchunk = 64;
-    dim3 g((unsigned)((n + BLOCK - 1) / BLOCK), (unsigned)((t_steps + tchunk - 1) / tchunk));
+    // 64 lanes x segments of PK_SEG steps: 65 536 lanes x 4 000 steps = 16 384 workgroups, 4 096 lanes still 1 024
+    dim3 g((unsigned)((n + PK_LANES - 1) / PK_LANES), (unsigned)((t_steps + PK_SEG - 1) / PK_SEG));
     if (h->record_mode == 2)
-        hipLaunchKernelGGL((k_pack_traj<E, 2>), g, dim3(BLOCK), 0, h->stream, h->d, n, tchunk, len, start, obs_all, act, rew, st_all, app, hid_all);
+        hipLaunchKernelGGL((k_pack_traj<E, 2>), g, dim3(BLOCK), 0, h->stream, h->d, n, len, start, obs_all, act, rew, st_all, app, hid_all);
     else
-        hipLaunchKernelGGL((k_pack_traj<E, 1>), g, dim3(BLOCK), 0, h->stream, h->d, n, tchunk, len, start, obs_all, act, rew, st_all, app, hid_all);
+        hipLaunchKernelGGL((k_pack_traj<E, 1>), g, dim3(BLOCK), 0, h->stream, h->d, n, len, start, obs_all, act, rew, st_all, app, hid_all);
 }
 #endif  // VS_TU_FAMILY
 
