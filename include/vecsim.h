@@ -293,7 +293,7 @@ int vs_set_policy_shape(vs_handle h, int shape);
  * (both int64, device memory).  Per-step destinations (act [total][A], rew [total], act_app [total][A]) take step t of rollout j
  * at row starts[j] + t; the destinations with one entry more than steps (obs_all [total + n][O], state_all [total + n][S],
  * hidden_all [total + n][H]: the value before every step and the final one, the latter from VS_OBS / VS_STATE / VS_HIDDEN of the
- * lane, frozen at its done) at row starts[j] + j + t.  All destinations row-major device memory; state_all / act_app / hidden_all
+ * lane, frozen at its done) at row starts[j] + j + t.  All destinations row-major device memory, 16-byte aligned; state_all / act_app / hidden_all
  * are read in record mode 2 only (hidden_all for H > 0).  Runs on the handle's stream.
  * Replaces: the histories rollout() returns per env -- P/sampling/rollout.py:305-325 (obs_hist / act_hist / rew_hist / state_hist /
  * act_app_hist / th_ddot_hist -> StepSequence) -- and their concatenation over rollouts, P/sampling/step_sequence.py:777-825. */

@@ -869,6 +869,8 @@ int vs_pack_traj(vs_handle h, int n_lanes, int t_steps, const int64_t* lengths, 
     if (!h || n_lanes < 1 || n_lanes > h->d.n || t_steps < 1 || !lengths || !starts || !obs_all || !act || !rew)
         return fail(h, VS_ERR_ARG, "vs_pack_traj: bad argument");
     if (!h->d.traj_rec || t_steps > h->traj_cap) return fail(h, VS_ERR_STATE, "vs_pack_traj: more steps than vs_set_traj_capacity holds");
+    for (const void* q : {(const void*)obs_all, (const void*)act, (const void*)rew, (const void*)state_all, (const void*)act_app, (const void*)hidden_all})
+        if (((uintptr_t)q & 15u) != 0) return fail(h, VS_ERR_ARG, "vs_pack_traj: destinations must be 16-byte aligned");
     if (h->record_mode == 2 && (!state_all || !act_app || (ENV_INFO[h->type].H > 0 && !hidden_all)))
         return fail(h, VS_ERR_ARG, "vs_pack_traj: record mode 2 needs the state / applied-action / hidden destinations");
     HIPCHK(h, hipSetDevice(h->device));

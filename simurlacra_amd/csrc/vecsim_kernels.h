@@ -2010,7 +2010,11 @@ __global__ __launch_bounds__(BLOCK) void k_pack_traj(Dev d, int n, const long lo
                                                      float* __restrict__ hid_all) {
     constexpr int F = Rec<E, REC>::F;
     constexpr int B = E::O + E::A + 1;
+#ifdef VS_PK_TT  // (experiments)
+    constexpr int TT = VS_PK_TT;
+#else
     constexpr int TT = F > 16 ? 8 : 16;   // steps per tile: 64 x TT x F floats of LDS (QQube, full records: 53 KB)
+#endif
     constexpr int RS = TT * F + 1;        // odd row stride: the load side writes a column across 64 rows without bank conflicts
     static_assert(BLOCK == 256 && PK_SEG % TT == 0, "four waves per workgroup");
     __shared__ float tile[PK_LANES * RS];
@@ -2039,12 +2043,18 @@ __global__ __launch_bounds__(BLOCK) void k_pack_traj(Dev d, int n, const long lo
     auto put = [&](float* __restrict__ dst, auto wc, auto c0c, int extra, int tb) __attribute__((always_inline)) {
         constexpr int W = decltype(wc)::value, C0 = decltype(c0c)::value;
         if constexpr (W > 0) {
-            for (int e = tid; e < PK_LANES * TT * W; e += BLOCK) {
-                const int ln = e / (TT * W), r = e - ln * (TT * W);
-                const int ts = r / W, f = r - ts * W;
+            // V floats per store: a row of W floats starts at a multiple of W * 4 bytes (16-B aligned destinations)
+            constexpr int V = W % 4 == 0 ? 4 : (W % 2 == 0 ? 2 : 1), WV = W / V;
+            for (int e = tid; e < PK_LANES * TT * WV; e += BLOCK) {
+                const int ln = e / (TT * WV), r = e - ln * (TT * WV);
+                const int ts = r / WV, fv = r - ts * WV;
                 if (tb + ts < l_len[ln]) {
                     const size_t row = (size_t)(l_row[ln] + tb + ts) + (extra ? (size_t)(lane0 + ln) : 0);
-                    dst[row * W + f] = tile[ln * RS + ts * F + C0 + f];
+                    const float* src = tile + ln * RS + ts * F + C0 + fv * V;
+                    float* dp = dst + row * W + fv * V;
+                    if constexpr (V == 4) *reinterpret_cast<float4*>(dp) = make_float4(src[0], src[1], src[2], src[3]);
+                    else if constexpr (V == 2) *reinterpret_cast<float2*>(dp) = make_float2(src[0], src[1]);
+                    else *dp = src[0];
                 }
             }
         }
