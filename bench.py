@@ -522,6 +522,25 @@ def roofline(args, env, local_rank, d, n, chunk, ms_region=None):
         roof["record2"] = {"kernel": env.rollout_variant(), "kernel_ms": ms2, "env_steps_per_s": units / (ms2 * 1e-3),
                            "alg_bytes_per_env_step": b2, "achieved": b2 * units / (ms2 * 1e-3) / 1e9,
                            "frac": b2 * units / (ms2 * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        # ... and the split of those records into rollouts (vs_pack_traj: time-major planes -> rollout-major packed arrays, what
+        # rollout() / StepSequence.concat hand to an algorithm): every lane one rollout of `chunk` steps
+        try:
+            env.set_traj_offset(0)
+            lengths = torch.full((n,), chunk, device=f"cuda:{local_rank}", dtype=torch.int64)
+            starts = torch.cumsum(lengths, 0) - lengths
+            for _ in range(2):
+                pk = env.pack_traj(n, chunk, lengths, starts, total=n * chunk)
+            env.sync()
+            env.timer_start()
+            for _ in range(5):
+                pk = env.pack_traj(n, chunk, lengths, starts, total=n * chunk)
+            msk = env.timer_stop() / 5
+            bk = 2 * 4 * env.traj_layout()[0]
+            roof["pack_traj"] = {"kernel": "k_pack_traj", "recorded_steps": units, "kernel_ms": msk, "alg_bytes_per_recorded_step": bk,
+                                 "achieved": bk * units / (msk * 1e-3) / 1e9, "frac": bk * units / (msk * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            del pk
+        except Exception as exc:  # the headline must not depend on this leg
+            roof["pack_traj"] = {"error": repr(exc)}
         env.set_record_mode(1)
     if args.mode == "fused" and args.env == "qq-su":
         # the HBM-bound point of this path: one vs_step launch over 16 777 216 envs, 117 algorithmic bytes
