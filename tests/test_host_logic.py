@@ -469,3 +469,23 @@ def test_fnn_policy_mirror_and_kernel_spec():
     for bad in (FNN(5, 1, [128], torch.tanh), FNN(5, 1, [8] * 5, torch.tanh), FNN(5, 1, [8], torch.nn.functional.elu),
                 FNN(5, 1, [8], torch.tanh, dropout=0.1), torch.nn.Linear(5, 1)):
         assert fnn_kernel_spec(bad) is None  # too wide / too deep / unknown nonlinearity / dropout / not an FNN
+
+
+def test_packed_rollouts_indexing():
+    """PackedRollouts: the slices of rollout j in the per-step tensors and in the tensors with one entry more than steps, the
+    rollout index of every packed step, per-rollout returns (CPU tensors: the container does not care where they live)"""
+    torch = pytest.importorskip("torch")
+    from simurlacra_amd.sampling import PackedRollouts
+
+    lengths = torch.tensor([3, 1, 4])
+    starts = torch.cumsum(lengths, 0) - lengths
+    total, n = int(lengths.sum()), 3
+    p = PackedRollouts(observations=torch.arange((total + n) * 2, dtype=torch.float32).reshape(total + n, 2),
+                       actions=torch.zeros(total, 1), rewards=torch.arange(total, dtype=torch.float32), states=None,
+                       actions_applied=None, th_ddot=None, lengths=lengths, offsets=torch.cat([starts, starts[-1:] + lengths[-1:]]),
+                       done_last=torch.tensor([True, False, True]), init_states=torch.zeros(n, 2), first_index=0)
+    assert len(p) == 3 and p.total_steps == 8
+    assert [p.step_slice(j) for j in range(3)] == [slice(0, 3), slice(3, 4), slice(4, 8)]
+    assert [p.obs_slice(j) for j in range(3)] == [slice(0, 4), slice(4, 6), slice(6, 11)]  # len + 1 entries each, back to back
+    assert p.rollout_index().tolist() == [0, 0, 0, 1, 2, 2, 2, 2]
+    assert p.undiscounted_returns().tolist() == [3.0, 3.0, 22.0]
