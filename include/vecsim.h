@@ -297,6 +297,10 @@ int vs_set_policy_shape(vs_handle h, int shape);
  * are read in record mode 2 only (hidden_all for H > 0).  Runs on the handle's stream.
  * Replaces: the histories rollout() returns per env -- P/sampling/rollout.py:305-325 (obs_hist / act_hist / rew_hist / state_hist /
  * act_app_hist / th_ddot_hist -> StepSequence) -- and their concatenation over rollouts, P/sampling/step_sequence.py:777-825. */
+/* Where the rollouts in the records end: lengths[j] = 1 + the first of rows 0 .. t_steps - 1 of VS_TRAJ_DONE whose done bit is set
+ * for lane j (t_steps if none is), done_last[j] = whether one is -- the step at which rollout()'s loop stops
+ * (`while not done and env.curr_step < env.max_steps`, P/sampling/rollout.py:185) and StepSequence.done[-1].  Device memory. */
+int vs_rollout_lengths(vs_handle h, int n_lanes, int t_steps, int64_t* lengths, uint8_t* done_last);
 int vs_pack_traj(vs_handle h, int n_lanes, int t_steps, const int64_t* lengths, const int64_t* starts, float* obs_all, float* act,
                  float* rew, float* state_all, float* act_app, float* hidden_all);
 /* The action stream of vs_step_random is Philox(seed; global env index, absolute step index); the handle counts the

@@ -6,6 +6,22 @@ namespace vs {
 
 __global__ void k_bump_row(int* row) { *row += 1; }
 
+// vs_rollout_lengths: per lane, the first recorded step whose done bit is set (words [t / 32][ld], bit t % 32)
+__global__ __launch_bounds__(256) void k_rollout_lengths(const uint32_t* __restrict__ words, size_t ld, int n, int t_steps,
+                                                         long long* __restrict__ lengths, uint8_t* __restrict__ done_last) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int nw = (t_steps + 31) / 32;
+    int first = -1;
+    for (int w = 0; w < nw && first < 0; ++w) {
+        uint32_t bits = words[(size_t)w * ld + i];
+        if (w == nw - 1 && (t_steps & 31)) bits &= (1u << (t_steps & 31)) - 1u;  // rows beyond t_steps are not part of it
+        if (bits) first = w * 32 + (__ffs((int)bits) - 1);
+    }
+    lengths[i] = first < 0 ? (long long)t_steps : (long long)first + 1;
+    done_last[i] = first >= 0;
+}
+
 __global__ void k_count_err(const uint8_t* err, int n, unsigned long long* out) {
     int i = blockIdx.x * BLOCK + threadIdx.x;
     bool e = i < n && err[i] != 0;
@@ -260,7 +276,7 @@ static int mixed_upload(vs_mixed* m, const float* const* acts, const int64_t* en
 
 extern "C" {
 
-int vs_version(void) { return 212; }
+int vs_version(void) { return 213; }
 
 static int record_width(int t, int mode) {
     const EnvInfo& e = ENV_INFO[t];
@@ -860,6 +876,17 @@ int vs_step_policy(vs_handle h, int k_steps, int record, uint64_t noise_seed) {
     if (record && h->d.traj_t0 + k_steps > h->traj_cap) return fail(h, VS_ERR_STATE, "vs_step_policy: traj offset + k_steps exceeds vs_set_traj_capacity");
     HIPCHK(h, hipSetDevice(h->device));
     DISPATCH_ENV(h->type, Launch<E>::rollout_fnn(h, k_steps, record ? h->record_mode : 0, noise_seed));
+    HIPCHK(h, hipGetLastError());
+    return VS_OK;
+}
+
+int vs_rollout_lengths(vs_handle h, int n_lanes, int t_steps, int64_t* lengths, uint8_t* done_last) {
+    if (!h || n_lanes < 1 || n_lanes > h->d.n || t_steps < 1 || !lengths || !done_last)
+        return fail(h, VS_ERR_ARG, "vs_rollout_lengths: bad argument");
+    if (!h->d.traj_done || t_steps > h->traj_cap) return fail(h, VS_ERR_STATE, "vs_rollout_lengths: more steps than vs_set_traj_capacity holds");
+    HIPCHK(h, hipSetDevice(h->device));
+    hipLaunchKernelGGL(k_rollout_lengths, dim3((unsigned)((n_lanes + 255) / 256)), dim3(256), 0, h->stream, (const uint32_t*)h->d.traj_done,
+                       (size_t)h->d.ld, n_lanes, t_steps, (long long*)lengths, done_last);
     HIPCHK(h, hipGetLastError());
     return VS_OK;
 }

@@ -472,11 +472,7 @@ class ParallelRolloutSampler:
         # at done (all three paths): VS_OBS / VS_STATE / VS_HIDDEN hold every lane's final observation and state.  One kernel
         # (vs_pack_traj) reads only the steps that belong to a rollout from the record planes and writes the packed arrays.
         T = t
-        done_T = v.traj_done(T, n)  # [T, n]
-        ar = torch.arange(n, device=dev)
-        any_done = done_T.any(dim=0)
-        first = torch.where(any_done, done_T.to(torch.uint8).argmax(dim=0), torch.full_like(ar, T - 1))
-        length = first + 1  # [n]
+        length, done_last_d = v.rollout_lengths(n, T)  # [n]: first done of every lane (or the records' end), from the bit words
         total = int(length.sum())  # the one size-dependent sync
         start = torch.cumsum(length, 0) - length
         pk = v.pack_traj(n, T, length, start, total=total)
@@ -490,12 +486,12 @@ class ParallelRolloutSampler:
                 observations=obs_all, actions=act_s.contiguous(), rewards=rew_s.contiguous(),
                 states=more[0] if more else None, actions_applied=more[1] if more else None,
                 th_ddot=more[2][:, 0] if qcp_dev else None, lengths=length, offsets=torch.cat([start, start[-1:] + length[-1:]]),
-                done_last=done_T[first, ar].bool(), init_states=state0.contiguous(), first_index=first_index,
+                done_last=done_last_d, init_states=state0.contiguous(), first_index=first_index,
                 env_name=base.name, dt=base.dt, param_names=v.param_names, domain_params=v.tensor(L.VS_PARAMS)[:, :n].t().clone())
         # device -> host through pinned staging buffers (a pageable .cpu() of ~70 MB runs at ~3 GB/s here), then one memcpy
         # each into arrays the caller owns
         host = self._to_host(
-            [obs_all, act_s.contiguous(), rew_s.contiguous(), done_T[first, ar].to(torch.uint8), length, state0.contiguous()]
+            [obs_all, act_s.contiguous(), rew_s.contiguous(), done_last_d.to(torch.uint8), length, state0.contiguous()]
             + more, out_dtypes=[None, None, np.float64] + [None] * (3 + len(more)))  # rewards: one conversion for all rollouts
         obs_p, act_p, rew_p, done_h, length_h, state0_h = host[:6]
         st_p, app_p, hid_p = (host[6], host[7], host[8] if H else None) if more else (None, None, None)

@@ -475,6 +475,18 @@ class VecSimEnv:
         planes, _ = self.traj_planes()
         return torch.cat([p[t_idx, lane_idx] for p, _ in planes], dim=1)
 
+    def rollout_lengths(self, n, t_steps):
+        """vs_rollout_lengths: (lengths [n] int64, done_last [n] bool) on the device -- a rollout ends with the first recorded
+        step whose done bit is set, or with the records"""
+        import torch
+
+        dev = f"cuda:{self.device}"
+        lengths = torch.empty(n, dtype=torch.int64, device=dev)
+        done_last = torch.empty(n, dtype=torch.uint8, device=dev)
+        self._check(self._lib.vs_rollout_lengths(self._h, int(n), int(t_steps), C.c_void_p(lengths.data_ptr()),
+                                                 C.c_void_p(done_last.data_ptr())), "vs_rollout_lengths")
+        return lengths, done_last.bool()
+
     def pack_traj(self, n, t_steps, lengths, starts, total=None):
         """vs_pack_traj: rollout j = the first lengths[j] recorded steps of lane j (j < n), packed one after the other on the
         device (lengths / starts: int64 device tensors, starts the exclusive cumulative sum).  Returns dict(obs [total + n, O],

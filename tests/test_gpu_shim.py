@@ -632,6 +632,11 @@ def test_pack_traj_kernel_equals_the_index_gather(vs, name, mode):
     done = tt["done"].bool()  # [T, n]
     ar = torch.arange(n, device=done.device)
     first = torch.where(done.any(0), done.to(torch.uint8).argmax(0), torch.full_like(ar, T - 1))
+    for Tq in (T, 100, 64, 33):  # vs_rollout_lengths: first set done bit of rows 0 .. Tq - 1 (rows beyond Tq masked out of the last word)
+        lens, dl = e.rollout_lengths(n, Tq)
+        dq = done[:Tq]
+        want_first = torch.where(dq.any(0), dq.to(torch.uint8).argmax(0), torch.full_like(ar, Tq - 1))
+        assert torch.equal(lens, want_first + 1) and torch.equal(dl, dq.any(0)), Tq
     length = torch.minimum(first + 1, 1 + (ar * 37) % T)  # (cut further, lane by lane: the kernel moves what the lengths say)
     start = torch.cumsum(length, 0) - length
     assert int(length.min()) == 1 and int(length.max()) > 64  # one-step and multi-chunk rollouts in one batch
