@@ -416,12 +416,17 @@ class ParallelRolloutSampler:
             # Consecutive launches fill ONE device-side trajectory buffer; nothing is copied to the host inside the loop.
             v.set_record_mode(2 if full else 1)
             v.set_traj_capacity(T_cap)
+            launches = 0
             while t < T_cap:
                 k = int(min(self._chunk, T_cap - t))
                 v.set_traj_offset(t)
                 v.step_random(k, seed=lane_key ^ 0xA0761D6478BD642F, record=True)
                 t += k
-                if bool(done_t.bool().all()):  # one scalar sync per launch
+                launches += 1
+                # one scalar sync per FOUR launches: a wave whose rollouts have all ended leaves the fused kernel at once, so
+                # up to three launches too many cost next to nothing, a host round trip per launch does (a third of a
+                # 4 096-rollout call)
+                if (launches & 3) == 0 and bool(done_t.bool().all()):
                     break
             v.set_traj_offset(0)
         elif fnn is not None:
