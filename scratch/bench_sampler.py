@@ -83,3 +83,17 @@ for name, kw, n in (("qq-su", dict(dt=0.004, max_steps=4000), 4096), ("qq-su", d
                 best = (steps, el)
         print(json.dumps(dict(env=name, policy=pol_name, output="sample_packed(): device tensors", rollouts=n, env_steps=best[0],
                               seconds=round(best[1], 4), env_steps_per_s=round(best[0] / best[1]))), flush=True)
+
+# a torch policy in the loop, eager against a replayed hipGraph of 32 iterations (graph_policy=True)
+env = vs.ENV_CLASSES["qq-su"](dt=0.004, max_steps=4000)
+torch.manual_seed(0)
+fnn = FNNPolicy(env.spec, [64, 64], torch.tanh, featurize=False)
+for tag, kw in (("eager", {}), ("hipGraph of 32 iterations", dict(graph_policy=True))):
+    s = ParallelRolloutSampler(env, fnn, 8, min_rollouts=4096, seed=0, fuse_policy=False, **kw)
+    s.sample()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    ros = s.sample()
+    el = time.perf_counter() - t0
+    steps = sum(len(r) for r in ros)
+    print(json.dumps(dict(env="qq-su", policy="FNNPolicy 64x64 tanh, torch in the loop: " + tag, rollouts=len(ros), env_steps=steps,
+                          seconds=round(el, 3), env_steps_per_s=round(steps / el))), flush=True)

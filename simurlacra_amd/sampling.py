@@ -241,7 +241,7 @@ class ParallelRolloutSampler:
 
     def __init__(self, env, policy, num_workers: int = 1, *, min_rollouts: int = None, min_steps: int = None,
                  show_progress_bar: bool = False, seed=NO_SEED, batch_lanes: int = 65536, chunk: int = 128,
-                 full_records: bool = True, fuse_policy: bool = True):
+                 full_records: bool = True, fuse_policy: bool = True, graph_policy: bool = False):
         if min_rollouts is None and min_steps is None:
             raise ValueErr(msg="At least one of min_rollouts and min_steps must be given")  # SamplerBase
         self.min_rollouts, self.min_steps = min_rollouts, min_steps
@@ -260,6 +260,10 @@ class ParallelRolloutSampler:
         # fuse_policy: evaluate FNN / FNNPolicy networks (optionally inside a NormalActNoiseExplStrat) in the rollout kernel
         # itself; False keeps every policy but DummyPolicy in torch (one recording step launch per env step)
         self._fuse_policy = bool(fuse_policy)
+        # graph_policy (opt-in): a policy that stays a torch module is stepped through a captured hipGraph of 32 (observation,
+        # policy, recording step) iterations instead of ~10 eager launches per env step -- for policies whose forward() is
+        # capturable (no host synchronisation, no data-dependent Python control flow)
+        self._graph_policy = bool(graph_policy)
         self._vecs = {}
 
     def _drop_handles(self):
@@ -376,18 +380,22 @@ class ParallelRolloutSampler:
                 v.set_param_buffer([ring.buffer] if isinstance(ring.buffer, dict) else ring.buffer, ring.selection)
         inits = [w[0] for w in work]
         v.set_auto_reset(False)
-        v.reset(seed=lane_key)  # init-space sample for every lane ...
-        if any(s is not None for s in inits):  # ... overridden by the explicit init states
-            width = {len(np.asarray(s).reshape(-1)) for s in inits if s is not None}
-            if len(width) != 1:
-                raise ValueErr(msg="all init states must have the same shape")
-            w_ = width.pop()
-            mask = np.array([s is not None for s in inits], dtype=np.uint8)
-            arr = np.zeros((n, w_), dtype=np.float32)
-            for j, s in enumerate(inits):
-                if s is not None:
-                    arr[j] = np.asarray(s, dtype=np.float32).reshape(-1)
-            v.reset(init_state=arr, mask=mask, seed=lane_key)
+
+        def reset_lanes():  # (a pure function of the seeds and the work list: the graph path calls it a second time)
+            v.reset(seed=lane_key)  # init-space sample for every lane ...
+            if any(s is not None for s in inits):  # ... overridden by the explicit init states
+                width = {len(np.asarray(s).reshape(-1)) for s in inits if s is not None}
+                if len(width) != 1:
+                    raise ValueErr(msg="all init states must have the same shape")
+                w_ = width.pop()
+                mask = np.array([s is not None for s in inits], dtype=np.uint8)
+                arr = np.zeros((n, w_), dtype=np.float32)
+                for j, s in enumerate(inits):
+                    if s is not None:
+                        arr[j] = np.asarray(s, dtype=np.float32).reshape(-1)
+                v.reset(init_state=arr, mask=mask, seed=lane_key)
+
+        reset_lanes()
         dev = f"cuda:{v.device}"
         obs_full = v.tensor(L.VS_OBS)[:, :n]
         keep = None if self._fc.keep.all() else torch.from_numpy(np.flatnonzero(self._fc.keep)).to(dev)
@@ -463,8 +471,46 @@ class ParallelRolloutSampler:
             # rollout() stops stepping an env at done (rollout.py:185): finished lanes are frozen by the step kernel, so
             # nothing the policy makes of their last observation can move them or raise their NaN flag
             v.set_freeze_done(True)
+            if self._graph_policy:
+                # one hipGraph of SEG iterations, replayed until every lane is done: the step kernel takes its record row from a
+                # device-side counter (vs_set_record_row), so a replay continues where the last one stopped
+                SEG = 32
+                v.set_traj_capacity((T_cap + SEG - 1) // SEG * SEG)
+
+                def one_step():
+                    obs_now = visible(obs_full, 0).t().contiguous()
+                    act = policy(obs_now).to(torch.float32).reshape(n, A).contiguous()
+                    v.step_record(act, row=None)
+
+                side = torch.cuda.Stream(device=dev)
+                side.wait_stream(torch.cuda.current_stream(v.device))
+                v.use_stream(side.cuda_stream)  # before the capture starts: stream switches synchronise
+                try:
+                    with torch.cuda.stream(side), torch.no_grad():
+                        v.set_record_row(0)
+                        for _ in range(2):  # warm-up of the policy's kernels (library handles, workspaces) ...
+                            one_step()
+                        side.synchronize()
+                        reset_lanes()       # ... undone: the same reset, lane for lane
+                        if hasattr(policy, "reset"):
+                            policy.reset()
+                        state0 = st_t.t().clone()
+                        v.set_record_row(0)
+                        side.synchronize()
+                        graph = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(graph, stream=side):
+                            for _ in range(SEG):
+                                one_step()
+                        while t < T_cap:
+                            graph.replay()
+                            t += SEG
+                            if bool(done_t.bool().all()):  # one scalar sync per replay
+                                break
+                    side.synchronize()
+                finally:
+                    v.use_stream(torch.cuda.current_stream(v.device).cuda_stream)
             with torch.no_grad():
-                while t < T_cap:
+                while t < T_cap and not self._graph_policy:
                     obs_now = visible(obs_full, 0).t().contiguous()  # [n, O']: what the policy sees
                     act = policy(obs_now).to(torch.float32).reshape(n, A).contiguous()
                     v.step_record(act, row=t)

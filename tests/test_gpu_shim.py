@@ -660,3 +660,30 @@ def test_pack_traj_kernel_equals_the_index_gather(vs, name, mode):
     if mode == 1:
         assert "state" not in pk
     e.close()
+
+
+@pytest.mark.parametrize("name", ["qq-su", "bob"])
+def test_graph_policy_path_equals_the_eager_one(vs, name):
+    """graph_policy=True: a torch policy stepped through a replayed hipGraph of 32 (observation, policy, recording step)
+    iterations -- a deterministic policy gives the same rollouts as the eager loop, field for field, bit for bit (warm-up steps
+    undone by the same reset; the record row comes from the device-side counter); max_steps not a multiple of 32"""
+    import torch
+
+    from simurlacra_amd.policies import FNNPolicy
+    from simurlacra_amd.sampling import ParallelRolloutSampler
+
+    env = vs.ENV_CLASSES[name](**dict(KW[name], max_steps=75))
+    torch.manual_seed(5)
+    pol = FNNPolicy(env.spec, [16, 16], torch.tanh, featurize=False)
+    a = ParallelRolloutSampler(env, pol, 2, min_rollouts=50, seed=3, fuse_policy=False).sample()
+    b = ParallelRolloutSampler(env, pol, 2, min_rollouts=50, seed=3, fuse_policy=False, graph_policy=True).sample()
+    c = ParallelRolloutSampler(env, pol, 2, min_rollouts=50, seed=3, fuse_policy=False, graph_policy=True).sample()  # (a second capture)
+    assert len(a) == len(b) == len(c) == 50 and (name == "qq-su" or len({len(r) for r in a}) > 1)  # (bob: rollouts of different lengths)
+    for ra, rb, rc in zip(a, b, c):
+        for other in (rb, rc):
+            assert len(ra) == len(other)
+            np.testing.assert_array_equal(ra.observations, other.observations)
+            np.testing.assert_array_equal(ra.actions, other.actions)
+            np.testing.assert_array_equal(ra.rewards, other.rewards)
+            np.testing.assert_array_equal(ra.states, other.states)
+            np.testing.assert_array_equal(ra.init_state, other.init_state)
