@@ -102,6 +102,22 @@ struct Dev {
 #define VS_STAMP(var)
 #endif
 
+// The lane index as a RARE block (reset, redraw, refill, the epilogue of a kernel) must see it: a value the optimiser has to
+// take as defined right here.  Every address such a block computes (VS_PARAMS / VS_CONSTS rows of the lane, the stock entry)
+// is loop-invariant, so LICM hoists the arithmetic out of the step loop and the results -- two VGPRs per 64-bit row address,
+// 33 rows for the cartpole's redraw -- stay live across the whole hot loop.  That, not the rare code's own needs, is what pushed
+// the auto-reset kernels of round 2 to their register caps and into scratch (cartpole: 256 VGPRs + 35 spills; with the index
+// laundered 131 and none; QQube headline kernel 168 + 8 -> 117).  An empty asm costs no instruction.
+__device__ __forceinline__ int cold_lane(int i) {
+    asm volatile("" : "+v"(i));
+    return i;
+}
+#ifdef VS_NO_COLD_LANE  // diagnostic builds only: the round-2 code generation
+#define VS_COLD(i) (i)
+#else
+#define VS_COLD(i) cold_lane(i)
+#endif
+
 // ------------------------------------------------------------------------------------------------- wrapper pipeline
 __device__ __forceinline__ void box_muller(uint32_t b0, uint32_t b1, float& z0, float& z1) { Rng::box_muller(b0, b1, z0, z1); }
 
@@ -397,6 +413,7 @@ template <class E, bool UNI>
 __device__ __forceinline__ void auto_reset(const Task& T, const Dev& d, bool fin, int i, uint64_t seed, float* c,
                                            float* s, float* h, int& step, float& ret, bool& yielded, EpStat& es) {
     if (__builtin_amdgcn_ballot_w64(fin) == 0ull) return;
+    i = VS_COLD(i);  // (see cold_lane: the addresses of this block are not to be carried through the caller's step loop)
     if (d.log_episodes) append_episode(d, fin, i, ret, step);
     if (fin) {
         es.count += 1u;
@@ -822,6 +839,7 @@ __device__ __forceinline__ void rollout_body(const Task& T, const Dev& d, int k_
         if (REC) E::observe(s, ob);
 #endif
     }
+    i = VS_COLD(i);  // the epilogue's addresses are the prologue's: recomputed here instead of carried through the loop
     if (!REC) E::observe(s, ob);
     if (PIPE && d.pipe.obs_on) pipe_obs<E>(d, i, es.epi, step, ob, ob);
 #pragma unroll
@@ -1414,6 +1432,7 @@ __global__ __launch_bounds__(NR * NE, NR == 3 ? 3 : E::WS_MIN_WAVES) void k_roll
     const int role = wave / (NE / 64);  // 0 P, 1 C, 2 G (NR == 3)
     const int le = threadIdx.x & (NE - 1);  // env slot inside the workgroup
     const int i = blockIdx.x * NE + le;
+    const int le_ = le, i_ = i;             // (for the rare blocks that shadow the two with laundered copies)
     const size_t ld = d.ld;
     const bool valid = i < d.n;
     const int nb = (k_steps + WS_R - 1) / WS_R;
@@ -1480,6 +1499,7 @@ __global__ __launch_bounds__(NR * NE, NR == 3 ? 3 : E::WS_MIN_WAVES) void k_roll
         if (G3) c_epi = __hip_atomic_load(&l_epi[le], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         const bool need = stock_on && valid && c_tag != c_epi;
         if (__builtin_amdgcn_ballot_w64(need) == 0ull) return;
+        const int i = VS_COLD(i_), le = VS_COLD(le_);  // shadow the kernel's: see cold_lane
         if (dr_stock) {
             // DomainRandWrapperLive.reset of episode c_epi: DomainRandomizer.randomize's draws in their order
             // (domain_parameter.py:104-132), statement for statement redraw_lane_params', straight into the entry
@@ -1619,6 +1639,7 @@ __global__ __launch_bounds__(NR * NE, NR == 3 ? 3 : E::WS_MIN_WAVES) void k_roll
                 if (AR) {
                     if (__builtin_amdgcn_ballot_w64(fin) != 0ull) {
                         VS_STAMP(sr0);
+                        const int i = VS_COLD(i_), le = VS_COLD(le_);  // shadow the kernel's: see cold_lane
                         if (fin) {
 #pragma unroll
                             for (int j = 0; j < E::S; ++j) err_acc |= isnan(s[j]);
@@ -1702,6 +1723,7 @@ __global__ __launch_bounds__(NR * NE, NR == 3 ? 3 : E::WS_MIN_WAVES) void k_roll
             q[1] = acc1, q[2] = acc2, q[3] = (unsigned long long)nb;  // (q[0]: the reset counters, accumulated over the launches)
         }
 #endif
+        const int i = VS_COLD(i_);  // (see cold_lane: the epilogue's addresses are not carried through the loop)
 #pragma unroll
         for (int j = 0; j < E::S; ++j) err_acc |= isnan(s[j]);
         if (err_acc && valid) d.err[i] = 1;
@@ -1863,6 +1885,7 @@ __global__ __launch_bounds__(NR * NE, NR == 3 ? 3 : E::WS_MIN_WAVES) void k_roll
         }
 #endif
         work(nb - 1);
+        const int i = VS_COLD(i_);
         d.ret[i] = ret;
         d.rew[i] = rew;
         if (E::FINAL != FINAL_NONE) d.yielded[i] = yielded;
