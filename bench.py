@@ -164,7 +164,7 @@ def _cpu_scalar_worker(args):
     return collected, rollouts, time.perf_counter() - t0
 
 
-def cpu_baseline(env_name, n_envs, budget_s=6.0, scalar_min_steps=100000):
+def cpu_baseline(env_name, n_envs, budget_s=None, scalar_min_steps=None):
     """CPU baseline beside the GPU number, on every core this job may use, BEFORE the GPU is touched
     (worker processes are forked from a process that has not initialised HIP):
       value             the oracle's NumPy port vectorised over the same 65 536-env workload, one process per core
@@ -172,11 +172,15 @@ def cpu_baseline(env_name, n_envs, budget_s=6.0, scalar_min_steps=100000):
                         until every worker has collected `scalar_min_steps` steps of complete rollouts"""
     import multiprocessing as mp
 
+    # (BENCH_CPU_BUDGET_S / BENCH_CPU_SCALAR_STEPS: the CPU tests shrink the sample; the defaults are ~10 s of CPU work)
+    budget_s = float(os.environ.get("BENCH_CPU_BUDGET_S", "6.0")) if budget_s is None else budget_s
+    scalar_min_steps = int(os.environ.get("BENCH_CPU_SCALAR_STEPS", "100000")) if scalar_min_steps is None else scalar_min_steps
+    floor_steps = int(os.environ.get("BENCH_CPU_SCALAR_FLOOR", "20000"))
     cores = usable_cores()
     share = max(1, n_envs // cores)
     # SURVEY 8(d): min_steps = 1e5 for the sampler as a whole; at least 20 000 per worker so that every worker times a few
     # dozen complete rollouts
-    scalar_min_steps = max(int(np.ceil(scalar_min_steps / cores)), 20000)
+    scalar_min_steps = max(int(np.ceil(scalar_min_steps / cores)), floor_steps)
     ctx = mp.get_context("fork")
     with ctx.Pool(cores) as pool:
         res = pool.map(_cpu_vector_worker, [(env_name, share, budget_s, r) for r in range(cores)])
@@ -206,15 +210,31 @@ def free_port():
         return s.getsockname()[1]
 
 
-def launch_ranks(n):
+def launch_ranks(n, args):
     """start n ranks of this very command as fresh child processes (this parent has made no GPU call and makes none),
-    relay their output, exit with their code"""
+    relay their output, exit with their code.  The CPU baseline of the line is timed HERE, on the box's host cores before any
+    rank exists (north_star: "next to the reference ParallelRolloutSampler timed on the box's host cores ... in the same run"),
+    and handed to rank 0 through a file."""
+    import tempfile
+
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(free_port()), os.path.abspath(__file__), *sys.argv[1:]]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this pool
     env.setdefault("OMP_NUM_THREADS", "1")
-    return subprocess.run(cmd, env=env).returncode
+    tmp = None
+    if not args.no_cpu_baseline:
+        base = cpu_baseline(args.env, min(args.envs, 65536))
+        base["timed_by"] = "launcher parent, before the ranks were started"
+        fd, tmp = tempfile.mkstemp(prefix="bench_cpu_baseline_", suffix=".json")
+        with os.fdopen(fd, "w") as f:
+            json.dump(base, f)
+        env["BENCH_CPU_BASELINE_JSON"] = tmp
+    try:
+        return subprocess.run(cmd, env=env).returncode
+    finally:
+        if tmp and os.path.exists(tmp):
+            os.remove(tmp)
 
 
 # ---------------------------------------------------------------------------------------------------------- one rank
@@ -329,13 +349,14 @@ def measure(args, rank, world, local_rank, dist, rehearsal):
 
     # pre-roll (untimed, before the W warm-up launches): the GPU comes out of the host-side set-up idle and its clock takes
     # some 10 ms of work to ramp -- a 20-launch timed region (1 ms) right behind a 5-launch warm-up would measure the ramp
-    if args.mode == "fused":
-        run(int(os.environ.get("BENCH_PREROLL", "400")))
+    preroll = int(os.environ.get("BENCH_PREROLL", "400")) if args.mode == "fused" else 0
+    if preroll:
+        run(preroll)
     run(max(args.warmup, 1))
     el = timed(steps)  # THE timed region: exactly `steps` launches between two barriers + synchronisations
     repeats = [timed(steps) for _ in range(3)]  # untimed by the contract: run-to-run spread of the same region
     cnt_t, rs_t, ls_t = (env.tensor(w)[0, :n] for w in (L.VS_EPSTAT_COUNT, L.VS_EPSTAT_RETSUM, L.VS_EPSTAT_LENSUM))
-    return dict(env=env, el=el, repeats=repeats, stats=(cnt_t, rs_t, ls_t), slots=slots, graph=graph is not None,
+    return dict(env=env, el=el, repeats=repeats, stats=(cnt_t, rs_t, ls_t), slots=slots, graph=graph is not None, preroll=preroll,
                 kernel_ms_timed_region=(ev_ms[0] / steps) if ev_ms else None,
                 kernel_ms_repeats=[e / steps for e in ev_ms[1:]])
 
@@ -344,7 +365,7 @@ def main():
     args = parse_args()
     dryrun = os.environ.get("BENCH_DRYRUN") == "1"
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(launch_ranks(args.gpus))  # the ranks are children; this process never initialises the GPU
+        sys.exit(launch_ranks(args.gpus, args))  # the ranks are children; this process never initialises the GPU
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -355,9 +376,17 @@ def main():
         args.steps = 1000 if args.mode == "fused" else 2000
     if args.warmup is None:
         args.warmup = 50 if args.mode == "fused" else 200
+    # the CPU baseline beside the GPU number, at every N: from the launcher parent's file when this command started its own
+    # ranks, else timed by rank 0 right here -- before its first HIP call (forked workers) and before the rendezvous, the
+    # other ranks wait for it in init_process_group
     cpu_base = None
-    if not args.no_cpu_baseline and world == 1 and not dryrun:
-        cpu_base = cpu_baseline(args.env, min(args.envs, 65536))  # before any HIP call (forked workers)
+    if not args.no_cpu_baseline and rank == 0:
+        handed = os.environ.get("BENCH_CPU_BASELINE_JSON")
+        if handed and os.path.exists(handed):
+            cpu_base = json.load(open(handed))
+        else:
+            cpu_base = cpu_baseline(args.env, min(args.envs, 65536))
+            cpu_base["timed_by"] = "rank 0, before its first GPU call"
 
     import torch
 
@@ -384,7 +413,7 @@ def main():
         # plumbing only: no device, no stepping -- the launch, the rendezvous, the collectives and the relay of rank 0's line
         if dist:
             dist.barrier()
-        m = dict(env=None, el=float("nan"), repeats=[], slots=0, graph=False,
+        m = dict(env=None, el=float("nan"), repeats=[], slots=0, graph=False, preroll=0,
                  stats=tuple(torch.full((4,), float(rank + 1)) for _ in range(3)))
     else:
         m = measure(args, rank, world, local_rank, dist, rehearsal)
@@ -417,7 +446,11 @@ def main():
         out = {
             "metric": METRIC,
             "value": None if dryrun else total_env_steps / el, "unit": "env-steps/s", "n_gpus": world, "steps": steps,
-            "warmup": args.warmup, "ms_per_step": el / steps * 1e3, "env_steps_per_step": per_step, "higher_is_better": True,
+            "warmup": args.warmup,
+            # untimed launches BEFORE the W warm-up launches (clock ramp after the host-side set-up; BENCH_PREROLL): no work of
+            # the timed region is skipped or cached by them, they are simply more warm-up
+            "preroll": m["preroll"],
+            "ms_per_step": el / steps * 1e3, "env_steps_per_step": per_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "timed_region_s": el,
             "repeat_ms_per_step": [r / steps * 1e3 for r in m["repeats"]],
@@ -452,6 +485,98 @@ def main():
     if dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+# BASELINE.json's other GPU configurations, one rank's shard each, as legs of the default line:
+# the same fused launch as the headline (400 env steps per launch, every step recorded, per-env constants, auto-reset, records
+# rotating through > 1 GiB), timed with HIP events on the kernel's stream.
+BASELINE_CONFIGS = [
+    dict(key="config2", what="QQubeSwingUpSim RK4, 4 096 envs, random policy", members=[("qq-su", 4096)], live_dr=0),
+    dict(key="config3", what="QCartPoleSwingUpSim + DomainRandWrapperLive (7 randomised params), 65 536 envs",
+         members=[("qcp-su", 65536)], live_dr=7),
+    dict(key="config4", what="QBallBalancerSim, 262 144 envs over 8 GPUs: one rank's 32 768", members=[("qbb", 32768)], live_dr=0),
+    dict(key="config5", what="mixed QQube + QCartPole + BallOnBeam, 1 M envs over 8 GPUs: one rank's 130 560 (43 520 each), one launch",
+         members=[("qq-su", 43520), ("qcp-su", 43520), ("bob", 43520)], live_dr=0),
+]
+
+
+def load_counters():
+    """profiles/rNN_counters.json: per-kernel PMC counters of this very command under rocprofv3 (separate --pmc passes),
+    committed once per round with the library version they are of; None when there is none for the loaded library"""
+    import glob
+
+    from simurlacra_amd import _lib as L
+
+    try:
+        tf = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_counters.json")))[-1]
+        tab = json.load(open(tf))
+        if tab.get("lib_version") == int(L.load().vs_version()):
+            tab["_source"] = os.path.basename(tf)
+            return tab
+    except Exception:
+        pass
+    return None
+
+
+def baseline_config_legs(local_rank, chunk, iters=100):
+    import simurlacra_amd as vs
+
+    counters = load_counters()
+    legs = {}
+    for cfg in BASELINE_CONFIGS:
+        try:
+            envs = []
+            for name, n in cfg["members"]:
+                kw = ENV_KW[name]
+                e = vs.VecSimEnv(name, n, device=local_rank, **kw)
+                e.set_params(np.tile(vs.nominal_params(name), (n, 1)))
+                if cfg["live_dr"]:
+                    rz = vs.create_default_randomizer(vs.ENV_CLASSES[name](**kw))
+                    e.set_randomizer(rz.device_specs()[: cfg["live_dr"]])
+                e.set_auto_reset(True, seed=11)
+                e.reset(seed=12)
+                e.set_record_mode(1)
+                slot_bytes = chunk * e.traj_layout()[0] * e.ld * 4
+                slots = max(1, min(8, int(np.ceil(RECORD_BUFFER_BYTES / len(cfg["members"]) / slot_bytes))))
+                e.set_traj_capacity(chunk * slots)
+                envs.append((e, slots))
+            n_tot = sum(n for _, n in cfg["members"])
+            b_per = sum(bytes_fused_step(DIMS[name], chunk, 1) * n for name, n in cfg["members"]) / n_tot
+            if len(envs) == 1:
+                e, slots = envs[0]
+                launches = [0]
+
+                def go(k):
+                    for _ in range(k):
+                        e.set_traj_offset((launches[0] % slots) * chunk)
+                        launches[0] += 1
+                        e.step_random(chunk, seed=13, record=True)
+
+                go(30)
+                e.sync()
+                e.timer_start()
+                go(iters)
+                ms = e.timer_stop() / iters
+                kname = e.rollout_variant()
+            else:
+                mixed = vs.MixedVecSimEnv([e for e, _ in envs])
+                ms = mixed.time_random(chunk, record=True, iters=iters)
+                kname = "k_rollout_mixed"
+            units = n_tot * chunk
+            ach = b_per * units / (ms * 1e-3) / 1e9
+            leg = {"config": cfg["what"], "kernel": kname, "envs": n_tot, "env_steps_per_launch": units, "kernel_ms": ms,
+                   "env_steps_per_s": units / (ms * 1e-3), "alg_bytes_per_env_step": b_per, "achieved": ach, "unit": "GB/s",
+                   "peak": HBM_PEAK_GBS, "frac": ach / HBM_PEAK_GBS}
+            if counters and cfg["key"] in counters:
+                leg["counters"] = dict(counters[cfg["key"]], source=counters["_source"])
+            legs[cfg["key"]] = leg
+            if len(envs) > 1:
+                mixed.close()
+            for e, _ in envs:
+                e.close()
+        except Exception as exc:  # the headline must not depend on these legs
+            legs[cfg["key"]] = {"config": cfg["what"], "error": repr(exc)}
+    return legs
 
 
 def roofline(args, env, local_rank, d, n, chunk, ms_region=None):
@@ -592,6 +717,11 @@ def roofline(args, env, local_rank, d, n, chunk, ms_region=None):
             pe.close()
         except Exception as exc:  # the headline must not depend on this leg
             roof["policy_fnn"] = {"error": repr(exc)}
+    if args.mode == "fused" and args.env == "qq-su" and n == 65536:
+        roof["configs"] = baseline_config_legs(local_rank, chunk)
+        cn = load_counters()
+        if cn and "headline" in cn:
+            roof["counters"] = dict(cn["headline"], source=cn["_source"])
     roof["note"] = ("at 65 536 envs there is one wave of envs per SIMD: the fused kernel runs three cooperating waves per 64 envs "
                     "(k_rollout_ws: physics | reward + records | action generator + first record plane); its record stream is a "
                     "pure write stream, whose ceiling on this GPU is `write_kernel_GBs`, not the 8 TB/s of `peak` (DESIGN.md "

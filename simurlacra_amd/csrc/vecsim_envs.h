@@ -250,6 +250,8 @@ struct EnvDefaults {
     static constexpr bool WS_G3 = false;
     // ... and how many waves per SIMD its two-role kernel must leave room for (the register budget the compiler gets: 512 / n)
     static constexpr int WS_MIN_WAVES = 1;
+    // ... and whether the two waves of its 64-env workgroups want a SIMD each (at most one wave per SIMD: see k_rollout_ws)
+    static constexpr bool WS_ALONE = false;
     // Env.limit_act -> BoxSpace.project_to (P/spaces/box.py:180-184); np.clip propagates NaN (fminf/fmaxf would drop it)
     template <class R>
     __device__ static void limit_act(const float*, const float* lo, const float* hi, const R* a_raw, R* a) {
@@ -756,6 +758,7 @@ struct Qbb : EnvDefaults<2> {
     // pre-processing the actions (WS_PREP_C) 62 against k_rollout's 100 us per 100 steps at 32 768 envs, 83 against 107 at 65 536
     static constexpr int WS_SHAPE_FULL = 256, WS_SMALL = 128;
     static constexpr bool WS_MID = false;
+    static constexpr bool WS_ALONE = true;
     enum { C_AM, C_BEQV, C_JEQ, C_CKIN, C_OFFX, C_OFFY, C_TXP, C_TXN, C_TYP, C_TYN, C_BDR2, C_JBR, C_MR2, C_CKMGR2,
            C_ZETA, C_XMAX, C_CMAX, C_IK_X0, C_IK_Y0 };
     static constexpr int CMAX = C_CMAX;

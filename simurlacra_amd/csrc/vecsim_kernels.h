@@ -1369,8 +1369,14 @@ __global__ __launch_bounds__(64 * fnn_waves(NHID)) void k_rollout_fnn(Task T, De
 // DP ("draw on P"): the policy's action generator runs on the physics wave and the action travels in the message instead of
 // through l_act -- for the families whose C wave is the longer one once it records (QQube: its share of observe() plus the
 // record stores outweigh the Philox block per four steps; measured with the per-role cycle stamps of -DVS_WS_STAMP).
+// Occupancy is part of the design: amdgpu_waves_per_eu(min, max) -- min: the register budget (three roles: three waves per
+// SIMD); max (0 = none): a family with E::WS_ALONE runs its 64-env workgroups ONE wave per SIMD (the kernel descriptor is
+// padded to 257 VGPRs): its physics wave is by far the long one and loses 15 % when the hardware, free to do so since the
+// kernel needs only 136 registers, puts both waves of a workgroup on one SIMD and leaves another idle
+// (scratch/ubench/place2.hip: 512 workgroups of 128 threads land as [PC][--][P-][-C] per compute unit, [P][C][P][C] when padded).
 template <class E, bool UNI, bool AR, int REC, int WS_R, int NE, bool DP, int NR = 2>
-__global__ __launch_bounds__(NR * NE, NR == 3 ? 3 : E::WS_MIN_WAVES) void k_rollout_ws(Task T, Dev d, int k_steps, uint64_t seed, uint64_t reset_seed,
+__global__ __launch_bounds__(NR * NE)
+__attribute__((amdgpu_waves_per_eu(NR == 3 ? 3 : E::WS_MIN_WAVES, (NE == 64 && NR == 2 && E::WS_ALONE) ? 1 : 0))) void k_rollout_ws(Task T, Dev d, int k_steps, uint64_t seed, uint64_t reset_seed,
                                                         uint64_t epoch0) {
     static_assert(E::FINAL != FINAL_STATE_TIME, "needs the post-step state on the reward side");
     static_assert(NE == 64 || NE == 128 || NE == 256, "envs per workgroup");
