@@ -58,6 +58,10 @@ ACT_HI = {"omo": 30.0, "bob": 29.43, "qq-su": 4.5, "qcp-su": 6.0, "qbb": 3.0, "q
           "bob-d": 29.43}
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_ACHIEVABLE_GBS = 6290.0  # what a float4 copy reaches there (79 % of spec)
+# vector-ALU issue peak: 1 024 SIMDs x one wave64 fp32 instruction per 2 cycles (SIMD-32) x 2.4 GHz (same guide: `v_fma_f32`
+# 2 cyc throughput per SIMD, 4 cyc issue for one wave alone; transcendentals 8, integer multiplies quarter rate -- a kernel that
+# mixes those in cannot reach it, and a SIMD with a single wave stops at half of it)
+VALU_PEAK_GINST_S = 1024 * 2.4 / 2.0 * 1e3 / 1e3  # 1 228.8 G wave-instructions / s
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense fp32 matrix rate (v_mfma_f32_32x32x2_f32: 64 FLOP/clk/SIMD = the fp32 vector rate), same guide
 DEFAULT_CHUNK = 400  # env steps per launch: the fixed cost of a launch (dispatch, pipeline fill and drain: ~6 us) is 3 % of it
 RECORD_BUFFER_BYTES = 1.25 * 2 ** 30  # rotating record buffer: > 1 GiB, several times the 256 MiB Infinity Cache
@@ -518,6 +522,38 @@ def load_counters():
     return None
 
 
+def valu_leg(cnt, kernel_ms):
+    """the vector-issue side of a leg's roofline from the PMC counters of its kernel (SQ_INSTS_VALU per launch, collected under
+    rocprofv3 in a separate pass of this command) and the launch duration measured live: for the kernels that are not HBM-bound"""
+    try:
+        per64 = cnt["derived"]["valu_insts_per_64_env_steps"]
+        insts = per64 * cnt["env_steps_per_launch"] / 64.0
+        ach = insts / (kernel_ms * 1e-3) / 1e9
+        out = {"bound": "valu-issue", "valu_insts_per_64_env_steps": per64, "achieved": ach, "peak": VALU_PEAK_GINST_S,
+               "unit": "G wave-instructions/s", "frac": ach / VALU_PEAK_GINST_S}
+        for k in ("salu_insts_per_64_env_steps", "lds_insts_per_64_env_steps", "valu_active_share_of_wave_cycles",
+                  "any_inst_active_share_of_wave_cycles", "wait_any_share_of_wave_cycles", "wait_inst_any_share_of_wave_cycles"):
+            if k in cnt["derived"]:
+                out[k] = cnt["derived"][k]
+        return out
+    except (KeyError, TypeError, ZeroDivisionError):
+        return None
+
+
+def counters_of(counters, key, kernel_ms):
+    if not counters or key not in counters:
+        return None
+    c = counters[key]
+    out = {"source": counters["_source"], "kernel": c.get("kernel")}
+    if "traffic_bytes_per_launch" in c:
+        out["traffic"] = c["traffic_bytes_per_launch"]
+        out["traffic_over_algorithmic"] = c["traffic_over_algorithmic"]
+    v = valu_leg(c, kernel_ms)
+    if v:
+        out["valu"] = v
+    return out
+
+
 def baseline_config_legs(local_rank, chunk, iters=100):
     import simurlacra_amd as vs
 
@@ -567,8 +603,9 @@ def baseline_config_legs(local_rank, chunk, iters=100):
             leg = {"config": cfg["what"], "kernel": kname, "envs": n_tot, "env_steps_per_launch": units, "kernel_ms": ms,
                    "env_steps_per_s": units / (ms * 1e-3), "alg_bytes_per_env_step": b_per, "achieved": ach, "unit": "GB/s",
                    "peak": HBM_PEAK_GBS, "frac": ach / HBM_PEAK_GBS}
-            if counters and cfg["key"] in counters:
-                leg["counters"] = dict(counters[cfg["key"]], source=counters["_source"])
+            cn = counters_of(counters, cfg["key"], ms)
+            if cn:
+                leg["counters"] = cn
             legs[cfg["key"]] = leg
             if len(envs) > 1:
                 mixed.close()
@@ -719,9 +756,11 @@ def roofline(args, env, local_rank, d, n, chunk, ms_region=None):
             roof["policy_fnn"] = {"error": repr(exc)}
     if args.mode == "fused" and args.env == "qq-su" and n == 65536:
         roof["configs"] = baseline_config_legs(local_rank, chunk)
-        cn = load_counters()
-        if cn and "headline" in cn:
-            roof["counters"] = dict(cn["headline"], source=cn["_source"])
+        cn = counters_of(load_counters(), "headline", ms)
+        if cn:
+            roof["counters"] = cn
+            if roof["traffic"] is None and "traffic" in cn:
+                roof["traffic"], roof["traffic_source"] = cn["traffic"], cn["source"]
     roof["note"] = ("at 65 536 envs there is one wave of envs per SIMD: the fused kernel runs three cooperating waves per 64 envs "
                     "(k_rollout_ws: physics | reward + records | action generator + first record plane); its record stream is a "
                     "pure write stream, whose ceiling on this GPU is `write_kernel_GBs`, not the 8 TB/s of `peak` (DESIGN.md "

@@ -27,7 +27,9 @@ def gather_episode_stats(count, retsum, lensum, group=None):
     import torch.distributed as dist
 
     mine = torch.stack([retsum.double().sum(), count.double().sum(), lensum.double().sum()])
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    # (with a process group the collective runs whatever its size: a one-rank RCCL communicator is the cheapest rehearsal of
+    # the library load / communicator set-up the 8-GPU run depends on, tests/test_gpu_rccl.py)
+    if dist.is_available() and dist.is_initialized():
         if dist.get_backend(group) == "gloo":
             mine = mine.cpu()  # CPU rehearsal of the multi-rank path; RCCL takes the device tensor as it is
         parts = [torch.zeros_like(mine) for _ in range(dist.get_world_size(group))]
@@ -46,7 +48,7 @@ def gather_returns(returns, group=None):
     import torch
     import torch.distributed as dist
 
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return returns.clone()
     out = torch.empty(dist.get_world_size(group) * returns.numel(), dtype=returns.dtype, device=returns.device)
     dist.all_gather_into_tensor(out, returns.contiguous(), group=group)

@@ -1042,50 +1042,71 @@ def test_step_jacobians_against_the_forks_autograd(vs, golden_dir):
     env.close()
 
 
-def test_headline_launch_values_at_65536(vs):
-    """The exact launch bench.py times -- 65 536 QQubeSwingUpSim envs, per-env constants, auto-reset, every step recorded,
-    bench.py's default steps per launch, the three-role k_rollout_ws in 256-env workgroups (one per compute unit) -- checked for
-    VALUES: records, final buffers and episode statistics equal the plain kernel's bit for bit (and every other shape's), 512 lanes of the last
-    recorded step are re-stepped by the fp64 oracle, and the record planes hold what rollout() keeps (mode 2)."""
+@pytest.mark.parametrize("mode", [1, 2])
+def test_headline_launch_values_at_65536(vs, mode):
+    """The exact launch bench.py times -- 65 536 QQubeSwingUpSim envs, per-env constants, auto-reset, every step recorded in
+    record mode 1 (`mode` = 1: the very template instantiation of the timed region, k_rollout_ws<QQT<0>, false, true, 1, 4, 256,
+    false, 3>) or 2, bench.py's default steps per launch, the records of consecutive launches ROTATING through three slots of the
+    record buffer as in bench.py (four launches: the fourth overwrites the first slot), the three-role k_rollout_ws in 256-env
+    workgroups (one per compute unit) -- checked for VALUES: records, done bits, final buffers and episode statistics equal the
+    plain kernel's bit for bit (and every other shape's); mode 2: 512 lanes of the last recorded step are re-stepped by the fp64
+    oracle and the record planes hold what rollout() keeps; mode 1: its [obs | act | rew] planes are the first planes of the
+    oracle-checked mode-2 records of the same launches, bit for bit."""
     L = vs._lib
     import bench
 
-    n, T = 65536, bench.DEFAULT_CHUNK
-    trio = {}
-    for variant in ("k_rollout",) + ws_variants("qq-su"):
+    n, T, slots, launches = 65536, bench.DEFAULT_CHUNK, 3, 4
+
+    def run(variant, rec_mode):
         e = vs.VecSimEnv("qq-su", n, **KW["qq-su"])
         e.set_params(np.tile(vs.nominal_params("qq-su"), (n, 1)))
         e.set_rollout_variant(variant)
         assert e.rollout_variant() == variant
         e.set_auto_reset(True, seed=1)
         e.reset(seed=2)
-        e.set_record_mode(2)
-        e.set_traj_capacity(2 * T)
-        e.step_random(T, seed=3, record=True)  # rows 0 .. T-1
-        e.set_traj_offset(T)
-        e.step_random(T, seed=3, record=True)  # rows T .. 2T-1: a second launch continues the streams
-        trio[variant] = e
+        e.set_record_mode(rec_mode)
+        e.set_traj_capacity(slots * T)
+        for l in range(launches):  # bench.py's run(): slot l % slots, the streams continue from launch to launch
+            e.set_traj_offset((l % slots) * T)
+            e.step_random(T, seed=3, record=True)
+        return e
+
     auto = vs.VecSimEnv("qq-su", n, **KW["qq-su"])
     assert auto.rollout_variant() == "k_rollout_ws256g"  # what the automatic choice (and bench.py) launches at this size
     auto.close()
-    a = trio["k_rollout"]
-    tt_a = a.traj_tensors(2 * T)
+    a = run("k_rollout", mode)
+    tt_a = a.traj_tensors(slots * T)
     for variant in ws_variants("qq-su"):
-        b = trio[variant]
-        tt_b = b.traj_tensors(2 * T)
+        b = run(variant, mode)
+        tt_b = b.traj_tensors(slots * T)
         for key in ("rec", "done"):
             assert torch.equal(tt_a[key], tt_b[key]), (variant, key)
         for which in (L.VS_STATE, L.VS_OBS, L.VS_STEPCOUNT, L.VS_RETURNS, L.VS_REW, L.VS_DONE, L.VS_FAILED,
                       L.VS_EPSTAT_COUNT, L.VS_EPSTAT_RETSUM, L.VS_EPSTAT_LENSUM):
             assert np.array_equal(a.get(which), b.get(which)), (variant, which)
         assert b.error_count() == 0
+        del tt_b
+        b.close()
     assert int(tt_a["done"].sum()) > 100  # episodes ended (and restarted) inside the window
-    # 512 lanes of the last recorded step against the fp64 oracle: recorded state + action -> reward, next state
+    if mode == 1:
+        # the lean records are the leading planes of the full ones: the same launches in record mode 2 (the oracle-checked form)
+        full = run("k_rollout_ws256g", 2)
+        tt_f = full.traj_tensors(slots * T)
+        for key in ("obs", "act", "rew", "done"):
+            assert torch.equal(tt_a[key], tt_f[key]), key
+        for which in (L.VS_STATE, L.VS_RETURNS, L.VS_EPSTAT_COUNT, L.VS_EPSTAT_RETSUM):
+            assert np.array_equal(a.get(which), full.get(which)), which
+        full.close()
+        a.close()
+        return
+    # 512 lanes of the last recorded step (launch 4 wrote slot 0: rows 0 .. T-1) against the fp64 oracle: recorded state +
+    # action -> reward, next state
     ref = cpu_ref.make_ref("qq-su", **KW["qq-su"])
     lanes = np.arange(0, n, n // 512)
-    last = {k: v[2 * T - 1][torch.from_numpy(lanes).cuda()].cpu().numpy().astype(np.float64) for k, v in tt_a.items()
+    row = ((launches - 1) % slots) * T + T - 1
+    last = {k: v[row][torch.from_numpy(lanes).cuda()].cpu().numpy().astype(np.float64) for k, v in tt_a.items()
             if k in ("state", "act", "rew", "obs", "act_app")}
-    done_last = tt_a["done"][2 * T - 1].cpu().numpy().astype(bool)[lanes]
+    done_last = tt_a["done"][row].cpu().numpy().astype(bool)[lanes]
     P = ref.nominal_params(len(lanes)).astype(np.float32).astype(np.float64)
     out = ref.step(last["state"], np.zeros((len(lanes), 0)), last["act"], P, np.zeros(len(lanes), dtype=np.int64))
     np.testing.assert_allclose(last["rew"], out["rew"], rtol=2e-5, atol=1e-12)
@@ -1095,8 +1116,61 @@ def test_headline_launch_values_at_65536(vs):
     got_next = a.get(L.VS_STATE)[lanes].astype(np.float64)
     assert keep.sum() > 400
     assert_state_close(ref, got_next[keep], out["state"][keep], P[keep])
-    for e in trio.values():
-        e.close()
+    a.close()
+
+
+def test_config3_launch_values_at_65536(vs):
+    """BASELINE config 3 as bench.py's `roofline.configs.config3` leg launches it -- 65 536 QCartPoleSwingUpSim envs, the first
+    seven parameters of the reference's default randomizer (default_randomizers.py:322-342) redrawn at every reset
+    (DomainRandWrapperLive), record mode 1, bench.py's steps per launch, records rotating through three slots -- in the
+    automatic kernel (k_rollout_ws in 64-env workgroups: reset stock with the pre-drawn parameters in LDS) and in 256-env
+    workgroups against the plain kernel: records, done bits, VS_PARAMS, VS_CONSTS, final buffers and episode statistics bit
+    for bit.  (Values against the reference: the golden step / reset cases and the randomizer tables, at small n.)"""
+    L = vs._lib
+    import bench
+
+    n, T, slots, launches = 65536, bench.DEFAULT_CHUNK, 3, 4
+    kw = KW["qcp-su"]
+    specs = vs.create_default_randomizer(vs.ENV_CLASSES["qcp-su"](**kw)).device_specs()[:7]
+    assert [sp[0] for sp in specs] == ["gravity_const", "cart_mass", "pole_mass", "rail_length", "pole_length",
+                                       "motor_efficiency", "gear_efficiency"]
+
+    def run(variant):
+        e = vs.VecSimEnv("qcp-su", n, **kw)
+        e.set_params(np.tile(vs.nominal_params("qcp-su"), (n, 1)))
+        e.set_randomizer(specs)
+        if variant:
+            e.set_rollout_variant(variant)
+        e.set_auto_reset(True, seed=11)
+        e.reset(seed=12)
+        e.set_record_mode(1)
+        e.set_traj_capacity(slots * T)
+        for l in range(launches):
+            e.set_traj_offset((l % slots) * T)
+            e.step_random(T, seed=13, record=True)
+        return e
+
+    auto = run(None)
+    assert auto.rollout_variant() == "k_rollout_ws64"  # the automatic choice at this size under a live randomizer
+    a = run("k_rollout")
+    tt_a = a.traj_tensors(slots * T)
+    cnt = a.episode_stats()[0]
+    assert cnt.sum() > n // 4 and int(tt_a["done"].sum()) > 1000  # the randomised rail length ends many episodes early
+    pa = a.get(L.VS_PARAMS)
+    rnd = [vs.param_names("qcp-su").index(sp[0]) for sp in specs]
+    reset_lanes = cnt > 0
+    assert all(len(np.unique(pa[reset_lanes][:, k])) > reset_lanes.sum() // 2 for k in rnd)
+    for b in (auto, run("k_rollout_ws")):
+        tt_b = b.traj_tensors(slots * T)
+        for key in ("rec", "done"):
+            assert torch.equal(tt_a[key], tt_b[key]), (b.rollout_variant(), key)
+        for which in (L.VS_STATE, L.VS_OBS, L.VS_HIDDEN, L.VS_STEPCOUNT, L.VS_RETURNS, L.VS_REW, L.VS_DONE, L.VS_FAILED,
+                      L.VS_PARAMS, L.VS_CONSTS, L.VS_EPSTAT_COUNT, L.VS_EPSTAT_RETSUM, L.VS_EPSTAT_LENSUM):
+            assert np.array_equal(a.get(which), b.get(which)), (b.rollout_variant(), which)
+        assert b.error_count() == 0
+        del tt_b
+        b.close()
+    a.close()
 
 
 def test_rollout_variant_selection(vs):
