@@ -256,6 +256,8 @@ def parse_args():
     ap.add_argument("--live-dr", type=int, default=0, help="DomainRandWrapperLive on the device: redraw the first K parameters "
                     "of the family's default randomizer at every reset (BASELINE config 3: qcp-su with K = 7)")
     ap.add_argument("--graph", type=int, default=0, help="step mode: capture `chunk` policy+step iterations in one hipGraph")
+    ap.add_argument("--lean-step", type=int, default=0, help="step mode: vs_set_lean_step (no running return, no failed byte: the "
+                    "117-B model of SURVEY 8(d) exactly; episode returns then read 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the large-N / full-record / probe legs (quick sweeps)")
     ap.add_argument("--seed", type=int, default=0)
@@ -282,6 +284,8 @@ def measure(args, rank, world, local_rank, dist, rehearsal):
     first, _ = shard(n * world, rank, world)
     env.set_index_offset(first)  # global env index: lane streams do not depend on the number of GPUs
     env.set_auto_reset(True, seed=args.seed * 1000 + 1)
+    if args.lean_step:
+        env.set_lean_step(True)
     env.reset(seed=args.seed * 7919 + 2)
     chunk = max(1, args.chunk)
     steps = args.steps
@@ -712,12 +716,13 @@ def roofline(args, env, local_rank, d, n, chunk, ms_region=None):
             big = vs.VecSimEnv(args.env, big_n, device=local_rank, **ENV_KW[args.env])
             big.set_params(np.tile(vs.nominal_params(args.env), (big_n, 1)))
             big.set_auto_reset(True, seed=5)
+            big.set_lean_step(True)  # what SimPyEnv.step returns and nothing else: the 117-B model of SURVEY 8(d) exactly
             big.reset(seed=6)
             act = (torch.rand(d["A"], big.ld, device=f"cuda:{local_rank}") * 2 - 1) * ACT_HI[args.env]
             torch.cuda.synchronize()
             msb = big.time_step_kernel(iters=8, actions=act)
             bb = bytes_single_step(d)
-            roof["large_n"] = {"kernel": "k_step", "envs": big_n, "kernel_ms": msb, "alg_bytes_per_env_step": bb,
+            roof["large_n"] = {"kernel": "k_step", "envs": big_n, "kernel_ms": msb, "alg_bytes_per_env_step": bb, "lean_step": True,
                                "env_steps_per_s": big_n / (msb * 1e-3), "achieved": bb * big_n / (msb * 1e-3) / 1e9,
                                "frac": bb * big_n / (msb * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                "frac_of_achievable": bb * big_n / (msb * 1e-3) / 1e9 / HBM_ACHIEVABLE_GBS}

@@ -101,6 +101,9 @@ enum vs_buffer {
                                      (P/environment_wrappers/action_normalization.py:66-75) */
 #define VS_FLAG_FREEZE_DONE 8     /* vs_set_freeze_done: vs_step leaves lanes alone whose done flag is set (rollout() stops at
                                      done, P/sampling/rollout.py:185); off by default -- env.step() after done keeps stepping */
+#define VS_FLAG_LEAN_STEP 16      /* vs_set_lean_step: vs_step returns what SimPyEnv.step returns -- (obs, rew, done),
+                                     P/environments/pysim/base.py:217-241 -- and keeps neither the running return VS_RETURNS nor
+                                     the VS_FAILED byte */
 
 /* Task / ctor configuration. Zero-initialise and set `use_defaults = 1` to get the reference defaults
  * (_create_task of each env).  Q and R are diagonal (all reference defaults are). */
@@ -317,6 +320,13 @@ int vs_record_mode(vs_handle h);
  * whose VS_DONE flag is set: state, observation, step counter and flags stay, VS_REW reads 0, and whatever action such a
  * lane is fed cannot raise its NaN flag.  Off (default): env.step() after done keeps stepping, as in the reference. */
 int vs_set_freeze_done(vs_handle h, int on);
+/* SimPyEnv.step returns (obs, rew, done, info) and nothing else (P/environments/pysim/base.py:217-241).  vs_step by default also
+ * keeps a running undiscounted return per env (VS_RETURNS, what the auto-reset books into VS_EPSTAT_RETSUM when an episode
+ * ends) and the VS_FAILED byte: 9 bytes per env step on top of the 117 algorithmic ones of SURVEY.md 8(d).  With lean on,
+ * vs_step reads and writes exactly that model: VS_RETURNS / VS_FAILED are left untouched (stale) and episodes that end under
+ * auto-reset count into VS_EPSTAT_COUNT / VS_EPSTAT_LENSUM with a return of 0.  vs_step_random / vs_step_policy are not
+ * affected (their returns live in registers).  Off by default. */
+int vs_set_lean_step(vs_handle h, int on);
 /* which kernel the next vs_step_random launches for this handle's configuration: 0 = k_rollout (one wave per 64 envs),
  * 1 = k_rollout_ws in 256-env workgroups, 2 = k_rollout_ws in 64-env workgroups (a physics wave and a reward/record wave
  * per 64 envs; chosen while the plain kernel would leave the SIMDs with a single wave, the small workgroups while the

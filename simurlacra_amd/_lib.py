@@ -10,7 +10,7 @@ ENV_TYPES = {"omo": 0, "bob": 1, "qq-su": 2, "qcp-su": 3, "qbb": 4, "qq-st": 5, 
 (VS_STATE, VS_OBS, VS_REW, VS_DONE, VS_HIDDEN, VS_STEPCOUNT, VS_ERRFLAG, VS_RETURNS, VS_PARAMS, VS_CONSTS,
  VS_EP_RETURNS, VS_EP_LENGTHS, VS_EP_ENVIDX, VS_EP_COUNT, VS_TRAJ_REC, _VS_RESERVED_15, _VS_RESERVED_16, VS_TRAJ_DONE,
  VS_FAILED, VS_EPSTAT_COUNT, VS_EPSTAT_RETSUM, VS_EPSTAT_LENSUM, VS_JAC_STATE, VS_JAC_REW, VS_JAC_OBS) = range(25)
-VS_FLAG_SIMPLE_DYNAMICS, VS_FLAG_LONG_POLE, VS_FLAG_ACT_NORM, VS_FLAG_FREEZE_DONE = 1, 2, 4, 8
+VS_FLAG_SIMPLE_DYNAMICS, VS_FLAG_LONG_POLE, VS_FLAG_ACT_NORM, VS_FLAG_FREEZE_DONE, VS_FLAG_LEAN_STEP = 1, 2, 4, 8, 16
 RV_PLAIN, RV_WS256, RV_WS64, RV_WS64G, RV_WS256G = 0, 1, 2, 3, 4  # vs_rollout_variant
 VS_NL_NONE, VS_NL_TANH, VS_NL_RELU, VS_NL_SIGMOID = 0, 1, 2, 3  # vs_fnn_desc nonlinearities
 VS_FNN_MAX_HIDDEN, VS_FNN_MAX_WIDTH = 4, 64
@@ -82,6 +82,7 @@ _SIGNATURES = {
     "vs_set_record_mode": (C.c_int, [_P, C.c_int]),
     "vs_record_mode": (C.c_int, [_P]),
     "vs_set_freeze_done": (C.c_int, [_P, C.c_int]),
+    "vs_set_lean_step": (C.c_int, [_P, C.c_int]),
     "vs_set_episode_log": (C.c_int, [_P, C.c_int]),
     "vs_clear_episodes": (C.c_int, [_P]),
     "vs_mixed_create": (C.c_int, [C.POINTER(_P), C.c_int, C.POINTER(_P)]),

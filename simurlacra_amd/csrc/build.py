@@ -53,6 +53,12 @@ def build(force=False, verbose=False, extra_flags=(), out=None, jobs=None):
     if not force and not extra_flags and out == OUT and not is_stale():
         return out
     hipcc = hipcc_path()
+    # a build with extra flags (diagnostic macros) never writes into the main object directory or over libvecsim.so: a later
+    # plain build() would see those objects as fresh and ship the instrumented code
+    if extra_flags and out == OUT:
+        import hashlib
+
+        out = os.path.join(HERE, "libvecsim_" + hashlib.sha1(" ".join(extra_flags).encode()).hexdigest()[:8] + ".so")
     obj_dir = OBJ_DIR if out == OUT else out + ".build"
     os.makedirs(obj_dir, exist_ok=True)
     todo = []

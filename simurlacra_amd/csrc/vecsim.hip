@@ -758,6 +758,13 @@ int vs_set_freeze_done(vs_handle h, int on) {
     return VS_OK;
 }
 
+int vs_set_lean_step(vs_handle h, int on) {
+    if (!h) return VS_ERR_ARG;
+    if (on) h->task.flags |= VS_FLAG_LEAN_STEP;
+    else h->task.flags &= ~VS_FLAG_LEAN_STEP;
+    return VS_OK;
+}
+
 int vs_set_rollout_variant(vs_handle h, int variant) {
     if (!h || variant < -1 || variant > 4) return fail(h, VS_ERR_ARG, "vs_set_rollout_variant: -1 (automatic) or 0 .. 4");
     h->rollout_variant = variant;

@@ -611,10 +611,13 @@ __device__ __forceinline__ void step_body(const Task& T, const Dev& d, const flo
         }
     }
 
-    float ret = d.ret[i] + o.rew;
+    // (vs_set_lean_step: exactly what SimPyEnv.step returns -- no running return, no failed byte; wave-uniform flag)
+    const bool lean = (T.flags & VS_FLAG_LEAN_STEP) != 0;
+    float ret = 0.f;
+    if (!lean) ret = d.ret[i] + o.rew;
     d.rew[i] = o.rew;
     d.done[i] = o.done;
-    d.failed[i] = o.failed;
+    if (!lean) d.failed[i] = o.failed;
     if (o.err && valid) d.err[i] = 1;  // sticky, write-only
 
     if (AR) {
@@ -645,7 +648,7 @@ __device__ __forceinline__ void step_body(const Task& T, const Dev& d, const flo
 #pragma unroll
     for (int j = 0; j < E::O; ++j) d.obs[j * ld + i] = ob[j];
     d.step[i] = step;
-    d.ret[i] = ret;
+    if (!lean) d.ret[i] = ret;
     if (E::FINAL != FINAL_NONE) d.yielded[i] = yielded;
 }
 

@@ -116,8 +116,11 @@ class FNNPolicy(Policy):
                  use_cuda=False, featurize=True):
         super().__init__(spec)
         self.featurize = bool(featurize)
+        # the reference's order (fnn.py:187-201): the net initialises once WITHOUT the kwargs, then the policy calls
+        # init_param(None, **init_param_kwargs) -- the same draws from torch's RNG as the reference under the same seed
         self.net = FNN(spec.obs_space.flat_dim + (1 if self.featurize else 0), spec.act_space.flat_dim, hidden_sizes,
-                       hidden_nonlin, dropout, output_nonlin, init_param_kwargs, use_cuda)
+                       hidden_nonlin, dropout, output_nonlin, None, use_cuda)
+        self.init_param(None, **(init_param_kwargs or {}))
 
     @property
     def param_values(self):
@@ -148,14 +151,17 @@ class NormalActNoiseExplStrat(Policy):
         self.policy = policy
         n = policy.env_spec.act_space.flat_dim
         std = torch.as_tensor(std_init, dtype=torch.float32).reshape(-1)
-        self.std = torch.clamp(std.expand(n).clone(), min=float(std_min))
+        # a buffer: policy.to(device) moves it (a pageable CPU tensor copied inside forward() is a synchronous host-to-device
+        # copy, illegal during the stream capture of ParallelRolloutSampler(graph_policy=True))
+        self.register_buffer("std", torch.clamp(std.expand(n).clone(), min=float(std_min)))
 
     def reset(self, **kwargs):
         self.policy.reset(**kwargs)
 
     def forward(self, obs):
         act = self.policy(obs)
-        return act + self.std.to(act.device, act.dtype) * torch.randn_like(act)
+        std = self.std if self.std.device == act.device else self.std.to(act.device)
+        return act + std.to(act.dtype) * torch.randn_like(act)
 
 
 _NONLIN_NAMES = {torch.tanh: "tanh", torch.nn.functional.tanh: "tanh", torch.relu: "relu", torch.nn.functional.relu: "relu",

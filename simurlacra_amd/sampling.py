@@ -241,7 +241,7 @@ class ParallelRolloutSampler:
 
     def __init__(self, env, policy, num_workers: int = 1, *, min_rollouts: int = None, min_steps: int = None,
                  show_progress_bar: bool = False, seed=NO_SEED, batch_lanes: int = 65536, chunk: int = 128,
-                 full_records: bool = True, fuse_policy: bool = True, graph_policy: bool = False):
+                 full_records: bool = True, fuse_policy: bool = True, graph_policy: bool = False, owned_arrays: bool = False):
         if min_rollouts is None and min_steps is None:
             raise ValueErr(msg="At least one of min_rollouts and min_steps must be given")  # SamplerBase
         self.min_rollouts, self.min_steps = min_rollouts, min_steps
@@ -264,12 +264,31 @@ class ParallelRolloutSampler:
         # policy, recording step) iterations instead of ~10 eager launches per env step -- for policies whose forward() is
         # capturable (no host synchronisation, no data-dependent Python control flow)
         self._graph_policy = bool(graph_policy)
+        # owned_arrays: the arrays of the rollouts sample() returns are pageable copies the caller owns.  Default (False): they
+        # are VIEWS of one page-locked block per field and call (~7.7 GB for 65 536 full-record QQube rollouts, 57 GB/s instead
+        # of 18) -- a block stays pinned as long as ANY rollout of that call is alive, and torch's caching host allocator keeps it
+        # afterwards: a caller that retains a few rollouts for long (a replay buffer, CVaRSampler's epsilon-fraction) should ask
+        # for owned arrays or copy what it keeps
+        self._owned = bool(owned_arrays)
         self._vecs = {}
 
     def _drop_handles(self):
         for v in self._vecs.values():
             v.close()
         self._vecs = {}
+
+    def close(self):
+        """release the device handles and the host-side conversion threads (idempotent)"""
+        self._drop_handles()
+        pool = self.__dict__.pop("_copy_pool", None)
+        if pool is not None:
+            pool.shutdown(wait=True)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def reinit(self, env=None, policy=None):
         if env is not None:
@@ -442,8 +461,9 @@ class ParallelRolloutSampler:
             # record inside ONE kernel, `chunk` steps per launch, lanes freeze at done; the same record planes as above
             if hasattr(self.policy, "reset"):
                 self.policy.reset()
-            if eval:
-                fnn = dict(fnn, noise_std=None)  # (the reference evaluates without exploration)
+            # (eval=True keeps the exploration noise, like every other path here and like the reference: rollout() only calls
+            # policy.eval(), and StochasticActionExplStrat.forward samples action_dist_at(act).rsample() whatever the mode,
+            # P/exploration/stochastic_action.py:80-96)
             v.set_policy_fnn(obs_idx=None if fc.keep.all() else np.flatnonzero(fc.keep), **fnn)
             v.set_record_mode(2 if full else 1)
             v.set_traj_capacity(T_cap)
@@ -471,53 +491,55 @@ class ParallelRolloutSampler:
             # rollout() stops stepping an env at done (rollout.py:185): finished lanes are frozen by the step kernel, so
             # nothing the policy makes of their last observation can move them or raise their NaN flag
             v.set_freeze_done(True)
-            if self._graph_policy:
-                # one hipGraph of SEG iterations, replayed until every lane is done: the step kernel takes its record row from a
-                # device-side counter (vs_set_record_row), so a replay continues where the last one stopped
-                SEG = 32
-                v.set_traj_capacity((T_cap + SEG - 1) // SEG * SEG)
+            try:
+                if self._graph_policy:
+                    # one hipGraph of SEG iterations, replayed until every lane is done: the step kernel takes its record row from a
+                    # device-side counter (vs_set_record_row), so a replay continues where the last one stopped
+                    SEG = 32
+                    v.set_traj_capacity((T_cap + SEG - 1) // SEG * SEG)
 
-                def one_step():
-                    obs_now = visible(obs_full, 0).t().contiguous()
-                    act = policy(obs_now).to(torch.float32).reshape(n, A).contiguous()
-                    v.step_record(act, row=None)
+                    def one_step():
+                        obs_now = visible(obs_full, 0).t().contiguous()
+                        act = policy(obs_now).to(torch.float32).reshape(n, A).contiguous()
+                        v.step_record(act, row=None)
 
-                side = torch.cuda.Stream(device=dev)
-                side.wait_stream(torch.cuda.current_stream(v.device))
-                v.use_stream(side.cuda_stream)  # before the capture starts: stream switches synchronise
-                try:
-                    with torch.cuda.stream(side), torch.no_grad():
-                        v.set_record_row(0)
-                        for _ in range(2):  # warm-up of the policy's kernels (library handles, workspaces) ...
-                            one_step()
-                        side.synchronize()
-                        reset_lanes()       # ... undone: the same reset, lane for lane
-                        if hasattr(policy, "reset"):
-                            policy.reset()
-                        state0 = st_t.t().clone()
-                        v.set_record_row(0)
-                        side.synchronize()
-                        graph = torch.cuda.CUDAGraph()
-                        with torch.cuda.graph(graph, stream=side):
-                            for _ in range(SEG):
+                    side = torch.cuda.Stream(device=dev)
+                    side.wait_stream(torch.cuda.current_stream(v.device))
+                    v.use_stream(side.cuda_stream)  # before the capture starts: stream switches synchronise
+                    try:
+                        with torch.cuda.stream(side), torch.no_grad():
+                            v.set_record_row(0)
+                            for _ in range(2):  # warm-up of the policy's kernels (library handles, workspaces) ...
                                 one_step()
-                        while t < T_cap:
-                            graph.replay()
-                            t += SEG
-                            if bool(done_t.bool().all()):  # one scalar sync per replay
-                                break
-                    side.synchronize()
-                finally:
-                    v.use_stream(torch.cuda.current_stream(v.device).cuda_stream)
-            with torch.no_grad():
-                while t < T_cap and not self._graph_policy:
-                    obs_now = visible(obs_full, 0).t().contiguous()  # [n, O']: what the policy sees
-                    act = policy(obs_now).to(torch.float32).reshape(n, A).contiguous()
-                    v.step_record(act, row=t)
-                    t += 1
-                    if (t % 32 == 0 or t == T_cap) and bool(done_t.bool().all()):  # one scalar sync per 32 steps
-                        break
-            v.set_freeze_done(False)
+                            side.synchronize()
+                            reset_lanes()       # ... undone: the same reset, lane for lane
+                            if hasattr(policy, "reset"):
+                                policy.reset()
+                            state0 = st_t.t().clone()
+                            v.set_record_row(0)
+                            side.synchronize()
+                            graph = torch.cuda.CUDAGraph()
+                            with torch.cuda.graph(graph, stream=side):
+                                for _ in range(SEG):
+                                    one_step()
+                            while t < T_cap:
+                                graph.replay()
+                                t += SEG
+                                if bool(done_t.bool().all()):  # one scalar sync per replay
+                                    break
+                        side.synchronize()
+                    finally:
+                        v.use_stream(torch.cuda.current_stream(v.device).cuda_stream)
+                with torch.no_grad():
+                    while t < T_cap and not self._graph_policy:
+                        obs_now = visible(obs_full, 0).t().contiguous()  # [n, O']: what the policy sees
+                        act = policy(obs_now).to(torch.float32).reshape(n, A).contiguous()
+                        v.step_record(act, row=t)
+                        t += 1
+                        if (t % 32 == 0 or t == T_cap) and bool(done_t.bool().all()):  # one scalar sync per 32 steps
+                            break
+            finally:
+                v.set_freeze_done(False)  # (also when the policy or the capture raises: the cached handle is reused)
         v.raise_on_error()
         # ---- split into rollouts on the device: rollout j = steps 0 .. first done of lane j, packed lane-major.  Lanes freeze
         # at done (all three paths): VS_OBS / VS_STATE / VS_HIDDEN hold every lane's final observation and state.  One kernel
@@ -595,7 +617,7 @@ class ParallelRolloutSampler:
         for k, (pinned, ev) in enumerate(staged):
             src = pinned.numpy()  # (keeps the pinned tensor alive)
             want = out_dtypes[k] if out_dtypes and out_dtypes[k] is not None else src.dtype
-            if np.dtype(want) == src.dtype:
+            if np.dtype(want) == src.dtype and not self._owned:
                 out.append(src)
                 continue
             dst = np.empty(src.shape, dtype=want)

@@ -398,6 +398,11 @@ class VecSimEnv:
         """step() leaves lanes alone whose done flag is set (rollout() stops at done); off: env.step() keeps stepping"""
         self._check(self._lib.vs_set_freeze_done(self._h, int(bool(on))), "vs_set_freeze_done")
 
+    def set_lean_step(self, on=True):
+        """step() keeps what SimPyEnv.step returns -- (obs, rew, done) -- and neither the running return VS_RETURNS nor the
+        VS_FAILED byte: exactly the 117 algorithmic bytes per QQube env step of SURVEY.md 8(d) (default: both are kept)"""
+        self._check(self._lib.vs_set_lean_step(self._h, int(bool(on))), "vs_set_lean_step")
+
     def set_traj_offset(self, t0=0):
         """first record row of the next recording step_random (consecutive launches fill one long buffer)"""
         self._check(self._lib.vs_set_traj_offset(self._h, int(t0)), "vs_set_traj_offset")

@@ -1173,6 +1173,34 @@ def test_config3_launch_values_at_65536(vs):
     a.close()
 
 
+def test_lean_step_is_the_step_without_the_bookkeeping(vs):
+    """vs_set_lean_step: vs_step returns what SimPyEnv.step returns (obs, rew, done: pysim/base.py:217-241) -- state,
+    observation, reward, done flag and step counter bit for bit those of the default kernel, with and without auto-reset;
+    VS_RETURNS and VS_FAILED are left alone, episodes still count (with a return of 0)"""
+    L = vs._lib
+    n = 3000
+    for ar in (False, True):
+        pair = []
+        for lean in (False, True):
+            e = vs.VecSimEnv("qq-st", n, dt=0.01, max_steps=20)
+            e.set_params(np.tile(vs.nominal_params("qq-st"), (n, 1)))
+            e.set_auto_reset(ar, seed=3)
+            e.reset(seed=4)
+            e.set_lean_step(lean)
+            torch.manual_seed(0)
+            for _ in range(45):
+                e.step((torch.rand(n, 1, device="cuda") * 2 - 1) * 6.0)
+            pair.append(e)
+        a, b = pair
+        for which in (L.VS_STATE, L.VS_OBS, L.VS_REW, L.VS_DONE, L.VS_STEPCOUNT, L.VS_EPSTAT_COUNT, L.VS_EPSTAT_LENSUM):
+            assert np.array_equal(a.get(which), b.get(which)), (ar, which)
+        assert np.abs(a.get(L.VS_RETURNS)).max() > 0 and np.abs(b.get(L.VS_RETURNS)).max() == 0  # untouched since the reset
+        assert (b.get(L.VS_FAILED) == 0).all() and (b.get(L.VS_EPSTAT_RETSUM) == 0).all()
+        if ar:
+            assert a.episode_stats()[0].sum() > n and np.abs(a.get(L.VS_EPSTAT_RETSUM)).max() > 0
+        a.close(), b.close()
+
+
 def test_rollout_variant_selection(vs):
     """automatic choice (Launch<E>::variant): the wave-specialised kernel while k_rollout would leave SIMDs with a single
     wave -- in 64-env workgroups up to 128 envs per compute unit (every family) and between 256 and 384, in the family's

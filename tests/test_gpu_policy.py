@@ -218,12 +218,21 @@ def test_sampler_takes_the_fused_policy_path(vs, envname):
         k = min(5, len(rf), len(rl))  # the first steps agree with the torch-in-the-loop path (before rounding differences grow)
         np.testing.assert_allclose(rf.observations[:k], rl.observations[:k], rtol=2e-4, atol=2e-5)
     assert worst < 1e-5
-    # with exploration noise: still the fused path; eval=True samples without it
+    # with exploration noise: still the fused path; eval=True keeps the noise -- like the reference (rollout() only calls
+    # policy.eval(); StochasticActionExplStrat.forward samples whatever the mode) and like the torch-in-the-loop path here
     noisy = NormalActNoiseExplStrat(policy, std_init=0.5)
     assert fnn_kernel_spec(noisy)["noise_std"] is not None
     smp = vs.ParallelRolloutSampler(env, noisy, 1, min_rollouts=64, seed=4)
     r_noise, r_eval = smp.sample(), smp.sample(eval=True)
-    with torch.no_grad():
-        m0 = pol(torch.from_numpy(np.asarray(r_noise[0].observations[:-1], dtype=np.float32))).numpy()
-        m1 = pol(torch.from_numpy(np.asarray(r_eval[0].observations[:-1], dtype=np.float32))).numpy()
-    assert np.abs(r_noise[0].actions - m0).max() > 1e-2 and np.abs(r_eval[0].actions - m1).max() < 1e-4
+    smp_torch = vs.ParallelRolloutSampler(env, noisy, 1, min_rollouts=64, seed=4, fuse_policy=False)
+    r_eval_torch = smp_torch.sample(eval=True)
+
+    def noise_of(rollouts):
+        pdev = next(pol.parameters()).device  # (the torch-in-the-loop sampler has moved the policy to the GPU)
+        with torch.no_grad():
+            return np.concatenate([ro.actions - pol(torch.from_numpy(np.asarray(ro.observations[:-1], dtype=np.float32)).to(pdev)).cpu().numpy()
+                                   for ro in rollouts]).ravel()
+
+    z_noise, z_eval, z_torch = noise_of(r_noise), noise_of(r_eval), noise_of(r_eval_torch)
+    for z in (z_noise, z_eval, z_torch):  # N(0, 0.5^2) on every path, evaluation mode or not
+        assert len(z) > 500 and abs(z.std() - 0.5) < 0.06 and abs(z.mean()) < 0.08, (len(z), z.std(), z.mean())
