@@ -701,7 +701,7 @@ def roofline(args, env, local_rank, d, n, chunk, ms_region=None):
             for _ in range(5):
                 pk = env.pack_traj(n, chunk, lengths, starts, total=n * chunk)
             msk = env.timer_stop() / 5
-            bk = 2 * 4 * env.traj_layout()[0]
+            bk = 2 * 4 * env.traj_layout()[0]  # every recorded float read once (time-major planes) and written once (row matrix)
             roof["pack_traj"] = {"kernel": "k_pack_traj", "recorded_steps": units, "kernel_ms": msk, "alg_bytes_per_recorded_step": bk,
                                  "achieved": bk * units / (msk * 1e-3) / 1e9, "frac": bk * units / (msk * 1e-3) / 1e9 / HBM_PEAK_GBS}
             del pk

@@ -291,21 +291,22 @@ int vs_step_policy(vs_handle h, int k_steps, int record, uint64_t noise_seed);
  * run shape 0 whatever is asked).  No counterpart in the reference (which evaluates the torch module, P/sampling/rollout.py:203-219);
  * the shapes differ in the summation order of a layer only. */
 int vs_set_policy_shape(vs_handle h, int shape);
-/* The recorded steps of lanes 0 .. n_lanes - 1 (rows 0 .. of VS_TRAJ_REC, vs_set_record_mode's layout) as ROLLOUTS: rollout j =
- * steps 0 .. lengths[j] - 1 of lane j, the rollouts packed one after the other, starts[j] = lengths[0] + .. + lengths[j - 1]
- * (both int64, device memory).  Per-step destinations (act [total][A], rew [total], act_app [total][A]) take step t of rollout j
- * at row starts[j] + t; the destinations with one entry more than steps (obs_all [total + n][O], state_all [total + n][S],
- * hidden_all [total + n][H]: the value before every step and the final one, the latter from VS_OBS / VS_STATE / VS_HIDDEN of the
- * lane, frozen at its done) at row starts[j] + j + t.  All destinations row-major device memory, 16-byte aligned; state_all / act_app / hidden_all
- * are read in record mode 2 only (hidden_all for H > 0).  Runs on the handle's stream.
+/* The recorded steps of lanes 0 .. n_lanes - 1 (rows 0 .. of VS_TRAJ_REC, vs_set_record_mode's layout) as ROLLOUTS in one row-major
+ * matrix rows[total + n_lanes][F] (F = vs_traj_layout's record width, device memory): rollout j = steps 0 .. lengths[j] - 1 of
+ * lane j, the rollouts one after the other, starts[j] = lengths[0] + .. + lengths[j - 1] (both int64, device memory).
+ *   rows[starts[j] + j + t]          the record of step t: [obs (O) | act (A) | rew | state (S) | act_app (A) | hidden (H)] (the last
+ *                                    three in record mode 2 only), t < lengths[j];
+ *   rows[starts[j] + j + lengths[j]] the entry behind the last step: final observation / state / hidden state from VS_OBS / VS_STATE /
+ *                                    VS_HIDDEN of the lane (frozen at its done), the per-step fields 0.
+ * Every field of a rollout is therefore a strided view of lengths[j] (per-step fields) or lengths[j] + 1 rows (observations, states,
+ * hidden states: the value before every step and the final one).  Runs on the handle's stream.
  * Replaces: the histories rollout() returns per env -- P/sampling/rollout.py:305-325 (obs_hist / act_hist / rew_hist / state_hist /
  * act_app_hist / th_ddot_hist -> StepSequence) -- and their concatenation over rollouts, P/sampling/step_sequence.py:777-825. */
 /* Where the rollouts in the records end: lengths[j] = 1 + the first of rows 0 .. t_steps - 1 of VS_TRAJ_DONE whose done bit is set
  * for lane j (t_steps if none is), done_last[j] = whether one is -- the step at which rollout()'s loop stops
  * (`while not done and env.curr_step < env.max_steps`, P/sampling/rollout.py:185) and StepSequence.done[-1].  Device memory. */
 int vs_rollout_lengths(vs_handle h, int n_lanes, int t_steps, int64_t* lengths, uint8_t* done_last);
-int vs_pack_traj(vs_handle h, int n_lanes, int t_steps, const int64_t* lengths, const int64_t* starts, float* obs_all, float* act,
-                 float* rew, float* state_all, float* act_app, float* hidden_all);
+int vs_pack_traj(vs_handle h, int n_lanes, int t_steps, const int64_t* lengths, const int64_t* starts, float* rows);
 /* The action stream of vs_step_random is Philox(seed; global env index, absolute step index); the handle counts the
  * steps it has taken.  vs_seek_random repositions that counter (0 = start of a fresh batch of rollouts). */
 int vs_seek_random(vs_handle h, uint64_t step_index);

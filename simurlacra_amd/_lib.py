@@ -74,7 +74,7 @@ _SIGNATURES = {
     "vs_step_policy": (C.c_int, [_P, C.c_int, C.c_int, C.c_uint64]),
     "vs_set_policy_shape": (C.c_int, [_P, C.c_int]),
     "vs_rollout_lengths": (C.c_int, [_P, C.c_int, C.c_int, _P, _P]),
-    "vs_pack_traj": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "vs_pack_traj": (C.c_int, [_P, C.c_int, C.c_int, _P, _P, _P]),
     "vs_rollout_variant": (C.c_int, [_P]),
     "vs_set_rollout_variant": (C.c_int, [_P, C.c_int]),
     "vs_set_traj_capacity": (C.c_int, [_P, C.c_int]),

@@ -898,18 +898,13 @@ int vs_rollout_lengths(vs_handle h, int n_lanes, int t_steps, int64_t* lengths, 
     return VS_OK;
 }
 
-int vs_pack_traj(vs_handle h, int n_lanes, int t_steps, const int64_t* lengths, const int64_t* starts, float* obs_all, float* act,
-                 float* rew, float* state_all, float* act_app, float* hidden_all) {
-    if (!h || n_lanes < 1 || n_lanes > h->d.n || t_steps < 1 || !lengths || !starts || !obs_all || !act || !rew)
+int vs_pack_traj(vs_handle h, int n_lanes, int t_steps, const int64_t* lengths, const int64_t* starts, float* rows) {
+    if (!h || n_lanes < 1 || n_lanes > h->d.n || t_steps < 1 || !lengths || !starts || !rows)
         return fail(h, VS_ERR_ARG, "vs_pack_traj: bad argument");
     if (!h->d.traj_rec || t_steps > h->traj_cap) return fail(h, VS_ERR_STATE, "vs_pack_traj: more steps than vs_set_traj_capacity holds");
-    for (const void* q : {(const void*)obs_all, (const void*)act, (const void*)rew, (const void*)state_all, (const void*)act_app, (const void*)hidden_all})
-        if (((uintptr_t)q & 15u) != 0) return fail(h, VS_ERR_ARG, "vs_pack_traj: destinations must be 16-byte aligned");
-    if (h->record_mode == 2 && (!state_all || !act_app || (ENV_INFO[h->type].H > 0 && !hidden_all)))
-        return fail(h, VS_ERR_ARG, "vs_pack_traj: record mode 2 needs the state / applied-action / hidden destinations");
+    if (((uintptr_t)rows & 3u) != 0) return fail(h, VS_ERR_ARG, "vs_pack_traj: the destination must be 4-byte aligned");
     HIPCHK(h, hipSetDevice(h->device));
-    DISPATCH_ENV(h->type, Launch<E>::pack_traj(h, n_lanes, t_steps, (const long long*)lengths, (const long long*)starts, obs_all, act,
-                                               rew, state_all, act_app, hidden_all));
+    DISPATCH_ENV(h->type, Launch<E>::pack_traj(h, n_lanes, t_steps, (const long long*)lengths, (const long long*)starts, rows));
     HIPCHK(h, hipGetLastError());
     return VS_OK;
 }

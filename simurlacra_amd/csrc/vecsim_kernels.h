@@ -1942,6 +1942,10 @@ __attribute__((amdgpu_waves_per_eu(NR == 3 ? 3 : E::WS_MIN_WAVES, (NE == 64 && N
             __builtin_amdgcn_s_waitcnt(0x0F70);
             draw(0);
             ws_barrier();
+#ifdef VS_WS_NOG  // diagnostic: the G wave only keeps the barriers (results are wrong)
+            for (int b = 0; b < nb; ++b) ws_barrier();
+            if (false)
+#endif
 #ifdef VS_WS_STAMP
             unsigned long long acc0 = 0, acc1 = 0, acc2 = 0;
 #endif
@@ -2022,24 +2026,23 @@ __global__ __launch_bounds__(BLOCK) void k_step_mixed(const Segs* __restrict__ s
 #endif  // VS_TU_MIXED
 
 // ------------------------------------------------------------------------------------------ rollouts out of the records
-// vs_pack_traj: the recorded steps of the first n lanes, time-major planes [t][plane][lane], into rollout-major arrays -- rollout
-// j = steps 0 .. len[j] - 1 of lane j, the rollouts one after the other (what rollout() returns per env, rollout.py:305-325, and
-// StepSequence.concat makes of many, step_sequence.py:777-825): per-step arrays (act, rew, act_app) at row start[j] + t, the
-// arrays with one entry more than steps (obs, state, hidden: the value before every step and the final one, read from
-// VS_OBS / VS_STATE / VS_HIDDEN of the frozen lane) at row start[j] + j + t.
+// vs_pack_traj: the recorded steps of the first n lanes, time-major planes [t][plane][lane], as ROLLOUTS -- rollout j = steps
+// 0 .. len[j] - 1 of lane j, the rollouts one after the other (what rollout() returns per env, rollout.py:305-325, and
+// StepSequence.concat makes of many, step_sequence.py:777-825) -- in ONE row-major matrix rows[total + n][F], F the record width:
+//   rows[start[j] + j + t] = the record of step t of rollout j  [obs | act | rew | state | act_app | hidden]   (t < len[j])
+//   rows[start[j] + j + len[j]] = the entry behind the last step: the final observation / state / hidden state (from VS_OBS /
+//                                 VS_STATE / VS_HIDDEN of the lane, frozen at its done), the per-step fields zero
+// so that every field of a rollout is a strided view of its len[j] (+ 1) rows.
 // A transpose through LDS: a workgroup owns 64 lanes and walks through a segment of PK_SEG steps in tiles of TT steps.  Load
 // side: for a given step the 64 lanes read 64 x 16 contiguous bytes per record plane (only lanes whose rollout reaches that
-// step).  Store side: in every destination a lane's TT steps are one contiguous run (obs of QQube: 16 x 24 B), and consecutive
-// threads write consecutive floats of it -- whole 256-B pieces per wave instruction instead of 64 scattered rows (the first
-// version of this kernel had a thread stream one lane, 4- to 24-B stores into 64 different lines per instruction: 1.3 TB/s);
-// runs that end inside a line are completed by the same workgroup's next tile.  HBM-bound: (F read + F written) x 4 B per step.
+// step).  Store side: a lane's TT steps are ONE contiguous run of TT x F floats in the destination (QQube, full records: 832 B)
+// and consecutive threads write consecutive floats of it.  Round 2 wrote six separate per-field arrays instead -- runs of 64 B
+// for the one-float fields (action, reward, applied action), 8-byte stores for the 6-float observation rows -- and stayed at
+// 0.46 of HBM; with one matrix every wave-level store is 256 contiguous bytes.  HBM-bound: (F read + F written) x 4 B per step.
 constexpr int PK_LANES = 64, PK_SEG = 256;
 template <class E, int REC>
 __global__ __launch_bounds__(BLOCK) void k_pack_traj(Dev d, int n, const long long* __restrict__ len,
-                                                     const long long* __restrict__ start, float* __restrict__ obs_all,
-                                                     float* __restrict__ act, float* __restrict__ rew,
-                                                     float* __restrict__ st_all, float* __restrict__ app,
-                                                     float* __restrict__ hid_all) {
+                                                     const long long* __restrict__ start, float* __restrict__ rows) {
     constexpr int F = Rec<E, REC>::F;
     constexpr int B = E::O + E::A + 1;
 #ifdef VS_PK_TT  // (experiments)
@@ -2047,10 +2050,11 @@ __global__ __launch_bounds__(BLOCK) void k_pack_traj(Dev d, int n, const long lo
 #else
     constexpr int TT = F > 16 ? 8 : 16;   // steps per tile: 64 x TT x F floats of LDS (QQube, full records: 53 KB)
 #endif
-    constexpr int RS = TT * F + 1;        // odd row stride: the load side writes a column across 64 rows without bank conflicts
-    static_assert(BLOCK == 256 && PK_SEG % TT == 0, "four waves per workgroup");
+    constexpr int RUN = TT * F;           // floats of a lane's run in the destination
+    constexpr int RS = RUN + 1;           // odd row stride: the load side writes a column across 64 rows without bank conflicts
+    static_assert(BLOCK == 256 && PK_SEG % TT == 0 && TT % 4 == 0, "four waves per workgroup");
     __shared__ float tile[PK_LANES * RS];
-    __shared__ long long l_row[PK_LANES];  // start[lane] of the workgroup's lanes
+    __shared__ long long l_row[PK_LANES];  // first destination row of the workgroup's lanes: start[lane] + lane
     __shared__ int l_len[PK_LANES];        // their rollout lengths (0 for lanes beyond n)
     __shared__ int l_max;
     const int lane0 = blockIdx.x * PK_LANES;
@@ -2062,7 +2066,7 @@ __global__ __launch_bounds__(BLOCK) void k_pack_traj(Dev d, int n, const long lo
         const int i = lane0 + tid;
         const int L = i < n ? (int)len[i] : 0;
         l_len[tid] = L;
-        l_row[tid] = i < n ? start[i] : 0;
+        l_row[tid] = i < n ? start[i] + (long long)i : 0;
         atomicMax(&l_max, L);
     }
     __syncthreads();
@@ -2070,61 +2074,50 @@ __global__ __launch_bounds__(BLOCK) void k_pack_traj(Dev d, int n, const long lo
     const int seg1 = min(seg0 + PK_SEG, l_max);
     const int i = lane0 + l;
     const int myL = l_len[l];
-    // the store side of one destination: W floats per step from column c0 of the record, rows `extra` = 1 for the arrays with
-    // one entry more than steps per rollout (their row index carries the rollout number as well)
-    auto put = [&](float* __restrict__ dst, auto wc, auto c0c, int extra, int tb) __attribute__((always_inline)) {
-        constexpr int W = decltype(wc)::value, C0 = decltype(c0c)::value;
-        if constexpr (W > 0) {
-            // V floats per store: a row of W floats starts at a multiple of W * 4 bytes (16-B aligned destinations)
-            constexpr int V = W % 4 == 0 ? 4 : (W % 2 == 0 ? 2 : 1), WV = W / V;
-            for (int e = tid; e < PK_LANES * TT * WV; e += BLOCK) {
-                const int ln = e / (TT * WV), r = e - ln * (TT * WV);
-                const int ts = r / WV, fv = r - ts * WV;
-                if (tb + ts < l_len[ln]) {
-                    const size_t row = (size_t)(l_row[ln] + tb + ts) + (extra ? (size_t)(lane0 + ln) : 0);
-                    const float* src = tile + ln * RS + ts * F + C0 + fv * V;
-                    float* dp = dst + row * W + fv * V;
-                    if constexpr (V == 4) *reinterpret_cast<float4*>(dp) = make_float4(src[0], src[1], src[2], src[3]);
-                    else if constexpr (V == 2) *reinterpret_cast<float2*>(dp) = make_float2(src[0], src[1]);
-                    else *dp = src[0];
-                }
-            }
+    // the records of tile k + 1 are loaded into registers BEFORE tile k's store side runs, and the two barriers of a tile wait
+    // for LDS traffic only (ws_barrier: lgkmcnt, not vmcnt): the global stores of a tile stay in flight behind it
+    constexpr int RPW = TT / 4;  // steps of a tile per wave on the load side
+    float v[RPW][F];
+    auto fetch = [&](int tb) __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const int t = tb + wave * RPW + r;
+            if (t < myL) Planes<F>::load(d.traj_rec + (size_t)t * F * ld, ld, i, v[r]);
         }
     };
+    if (seg0 < seg1) fetch(seg0);
     for (int tb = seg0; tb < seg1; tb += TT) {
-        // ---- load side: wave w takes steps tb + w * (TT / 4) .. of the tile, a lane its own record
+        // ---- load side: wave w took steps tb + w * (TT / 4) .. of the tile, a lane its own record
 #pragma unroll
-        for (int r = 0; r < TT / 4; ++r) {
-            const int ts = wave * (TT / 4) + r, t = tb + ts;
-            if (t < myL) {
-                float v[F];
-                Planes<F>::load(d.traj_rec + (size_t)t * F * ld, ld, i, v);
+        for (int r = 0; r < RPW; ++r) {
+            const int ts = wave * RPW + r;
+            if (tb + ts < myL) {
 #pragma unroll
-                for (int f = 0; f < F; ++f) tile[l * RS + ts * F + f] = v[f];
+                for (int f = 0; f < F; ++f) tile[l * RS + ts * F + f] = v[r][f];
             }
         }
-        __syncthreads();
-        // ---- store side
-        put(obs_all, std::integral_constant<int, E::O>{}, std::integral_constant<int, 0>{}, 1, tb);
-        put(act, std::integral_constant<int, E::A>{}, std::integral_constant<int, E::O>{}, 0, tb);
-        put(rew, std::integral_constant<int, 1>{}, std::integral_constant<int, E::O + E::A>{}, 0, tb);
-        if constexpr (REC == 2) {
-            put(st_all, std::integral_constant<int, E::S>{}, std::integral_constant<int, B>{}, 1, tb);
-            put(app, std::integral_constant<int, E::A>{}, std::integral_constant<int, B + E::S>{}, 0, tb);
-            put(hid_all, std::integral_constant<int, E::H>{}, std::integral_constant<int, B + E::S + E::A>{}, 1, tb);
+        ws_barrier();
+        if (tb + TT < seg1) fetch(tb + TT);  // (in flight while this tile is stored)
+        // ---- store side: lane ln's run of min(TT, len - tb) x F floats, thread by thread
+        for (int e = tid; e < PK_LANES * RUN; e += BLOCK) {
+            const int ln = e / RUN, r = e - ln * RUN;
+            const int nv = min(TT, l_len[ln] - tb) * F;
+            if (r < nv) rows[(size_t)(l_row[ln] + tb) * F + r] = tile[ln * RS + r];
         }
-        __syncthreads();
+        ws_barrier();  // the tile has been read (LDS only: the global stores stay in flight)
     }
     // ---- the entry behind a rollout's last step: the frozen lane's final observation / state (by the segment that holds it)
     if (wave == 0 && myL > 0 && myL - 1 >= seg0 && myL - 1 < seg0 + PK_SEG) {
-        const size_t ko = (size_t)(l_row[l] + myL) + (size_t)i;
+        float* fin = rows + (size_t)(l_row[l] + myL) * F;
 #pragma unroll
-        for (int j = 0; j < E::O; ++j) obs_all[ko * E::O + j] = d.obs[j * ld + i];
+        for (int f = 0; f < F; ++f) fin[f] = 0.f;
+#pragma unroll
+        for (int j = 0; j < E::O; ++j) fin[j] = d.obs[j * ld + i];
         if constexpr (REC == 2) {
 #pragma unroll
-            for (int j = 0; j < E::S; ++j) st_all[ko * E::S + j] = d.state[j * ld + i];
+            for (int j = 0; j < E::S; ++j) fin[B + j] = d.state[j * ld + i];
 #pragma unroll
-            for (int j = 0; j < E::H; ++j) hid_all[ko * E::H + j] = d.hidden[j * ld + i];
+            for (int j = 0; j < E::H; ++j) fin[B + E::S + E::A + j] = d.hidden[j * ld + i];
         }
     }
 }
@@ -2284,8 +2277,7 @@ struct Launch {
     static void sample_params(vs_env* h, uint64_t seed, const uint8_t* mask);
     static void reset(vs_env* h, const float* init, long pitch, int full, const uint8_t* mask, uint64_t seed);
     static void observe(vs_env* h);
-    static void pack_traj(vs_env* h, int n, int t_steps, const long long* len, const long long* start, float* obs_all, float* act,
-                          float* rew, float* st_all, float* app, float* hid_all);  // vs_pack_traj
+    static void pack_traj(vs_env* h, int n, int t_steps, const long long* len, const long long* start, float* rows);  // vs_pack_traj
 };
 
 // mixed batches: defined in vecsim_mixed.hip
@@ -2470,14 +2462,11 @@ void Launch<E>::observe(vs_env* h) {
 }
 
 template <class E>
-void Launch<E>::pack_traj(vs_env* h, int n, int t_steps, const long long* len, const long long* start, float* obs_all, float* act,
-                          float* rew, float* st_all, float* app, float* hid_all) {
+void Launch<E>::pack_traj(vs_env* h, int n, int t_steps, const long long* len, const long long* start, float* rows) {
     // 64 lanes x segments of PK_SEG steps: 65 536 lanes x 4 000 steps = 16 384 workgroups, 4 096 lanes still 1 024
     dim3 g((unsigned)((n + PK_LANES - 1) / PK_LANES), (unsigned)((t_steps + PK_SEG - 1) / PK_SEG));
-    if (h->record_mode == 2)
-        hipLaunchKernelGGL((k_pack_traj<E, 2>), g, dim3(BLOCK), 0, h->stream, h->d, n, len, start, obs_all, act, rew, st_all, app, hid_all);
-    else
-        hipLaunchKernelGGL((k_pack_traj<E, 1>), g, dim3(BLOCK), 0, h->stream, h->d, n, len, start, obs_all, act, rew, st_all, app, hid_all);
+    if (h->record_mode == 2) hipLaunchKernelGGL((k_pack_traj<E, 2>), g, dim3(BLOCK), 0, h->stream, h->d, n, len, start, rows);
+    else hipLaunchKernelGGL((k_pack_traj<E, 1>), g, dim3(BLOCK), 0, h->stream, h->d, n, len, start, rows);
 }
 #endif  // VS_TU_FAMILY
 

@@ -116,6 +116,9 @@ class StepSequence:
         return f"StepSequence(len={self.length}, return={self.undiscounted_return():.4g})"
 
 
+_PLAIN_WORK = (None, None)  # a rollout without an explicit init state or domain parameters
+
+
 class PackedRollouts:
     """The rollouts of one batch of lanes as packed DEVICE tensors -- what `ParallelRolloutSampler.sample()` holds right before it
     copies to the host and cuts `StepSequence`s, handed out as it is (`sample_packed()`): nothing crosses PCIe and no per-rollout
@@ -123,13 +126,19 @@ class PackedRollouts:
     algorithms build with `StepSequence.concat`, P/sampling/step_sequence.py:777-825 -- which drops every rollout's final observation
     and state (truncate_last); here they are kept).
 
-    Rollout j (j = 0 .. n - 1, in rollout order) owns steps `offsets[j] : offsets[j + 1]` of the per-step tensors and entries
-    `offsets[j] + j : offsets[j + 1] + j + 1` of the tensors with one entry more than steps (observations, states, th_ddot):
+    ONE matrix `rows` [total + n, F] holds everything (round 3; six separate arrays before): rollout j (j = 0 .. n - 1, in rollout
+    order) owns rows `offsets[j] + j : offsets[j + 1] + j + 1` -- its `lengths[j]` steps and, last, the entry behind them (final
+    observation / state / hidden state; the per-step fields of that row are 0) -- and every field is a strided VIEW of it, all
+    indexed by the same rows:
 
-      observations [total + n, O]   actions [total, A]   rewards [total] (float32)
-      states [total + n, S] | None  actions_applied [total, A] | None   th_ddot [total + n] | None  (full records)
-      lengths [n] (int64)   offsets [n + 1] (int64)   done_last [n] (bool: the rollout ended by done, not by the step limit)
+      observations [total + n, O]   actions [total + n, A]   rewards [total + n] (float32)
+      states [total + n, S] | None  actions_applied [total + n, A] | None   th_ddot [total + n] | None  (full records)
+      lengths [n] (int64)   offsets [n + 1] (int64: exclusive cumulative lengths)   total = offsets[n]
+      done_last [n] (bool: the rollout ended by done, not by the step limit)
       init_states [n, S]    first_index: rollout number of rollout 0 within the sample() call
+
+    `step_slice(j)` are the rows of rollout j's steps, `obs_slice(j)` those plus the final entry; `step_rows()` the row indices of
+    all steps (for a dense, reference-style concatenation: `p.actions[p.step_rows()]`).
     """
 
     def __init__(self, **kw):
@@ -140,13 +149,21 @@ class PackedRollouts:
 
     @property
     def total_steps(self) -> int:
-        return int(self.actions.shape[0])
+        return int(self.total)
 
     def step_slice(self, j: int) -> slice:
-        return slice(int(self.offsets[j]), int(self.offsets[j + 1]))
+        a = int(self.offsets[j]) + j
+        return slice(a, a + int(self.lengths[j]))
 
     def obs_slice(self, j: int) -> slice:
         return slice(int(self.offsets[j]) + j, int(self.offsets[j + 1]) + j + 1)
+
+    def row_rollout_index(self):
+        """[total + n] int64: the rollout every ROW (steps and final entries) belongs to"""
+        import torch
+
+        return torch.repeat_interleave(torch.arange(len(self), device=self.lengths.device), self.lengths + 1,
+                                       output_size=self.total_steps + len(self))
 
     def rollout_index(self):
         """[total] int64: the rollout every packed step belongs to"""
@@ -155,12 +172,18 @@ class PackedRollouts:
         return torch.repeat_interleave(torch.arange(len(self), device=self.lengths.device), self.lengths,
                                        output_size=self.total_steps)
 
+    def step_rows(self):
+        """[total] int64: the row of every step, rollout after rollout (the rows without the final entries)"""
+        import torch
+
+        return torch.arange(self.total_steps, device=self.lengths.device) + self.rollout_index()
+
     def undiscounted_returns(self):
-        """[n] float32 on the device"""
+        """[n] float32 on the device (the final entries carry a reward of 0)"""
         import torch
 
         out = torch.zeros(len(self), device=self.rewards.device, dtype=self.rewards.dtype)
-        return out.index_add_(0, self.rollout_index(), self.rewards)
+        return out.index_add_(0, self.row_rollout_index(), self.rewards)
 
 
 def rollout(env, policy, eval: bool = False, max_steps: Optional[int] = None, reset_kwargs: Optional[dict] = None,
@@ -308,7 +331,7 @@ class ParallelRolloutSampler:
         """[(init_state | None, domain_param | None)] in rollout order (parallel_rollout_sampler.py:280-304)"""
         n = self.min_rollouts
         if init_states is None and domain_params is None:
-            return [(None, None)] * n
+            return [_PLAIN_WORK] * n
         if init_states is not None and domain_params is None:
             rep = ceil(n / len(init_states))
             return [(s, None) for s in rep * list(init_states)]
@@ -351,7 +374,7 @@ class ParallelRolloutSampler:
         self._fc = fuse_wrappers(self.env)  # ActNorm / act noise / act delay / obs norm / obs noise / partial obs
         return v
 
-    def _run_batch(self, work, first_index, eval, packed_out=False):
+    def _run_batch(self, work, first_index, eval, packed_out=False, plain=False):
         """run len(work) rollouts as lanes; returns List[StepSequence] in order (packed_out: one PackedRollouts)"""
         import torch
 
@@ -361,11 +384,11 @@ class ParallelRolloutSampler:
         # current stream for the duration of the batch (pointer 0 = the legacy default stream)
         v.use_stream(torch.cuda.current_stream(v.device).cuda_stream)
         try:
-            return self._run_batch_on_stream(v, work, first_index, eval, packed_out)
+            return self._run_batch_on_stream(v, work, first_index, eval, packed_out, plain)
         finally:
             v.use_stream(None)
 
-    def _run_batch_on_stream(self, v, work, first_index, eval, packed_out=False):
+    def _run_batch_on_stream(self, v, work, first_index, eval, packed_out=False, plain=False):
         import torch
 
         n = len(work)
@@ -381,9 +404,12 @@ class ParallelRolloutSampler:
         v.set_index_offset(first_index)
         v.seek_random(0)
         self._fc.apply(v, seed=lane_key)  # the wrappers of the chain, fused into the kernels; noise keyed per sample() call
-        dps = [w[1] for w in work]
+        # (`plain`: the caller passed neither init states nor domain parameters -- every entry of the work list is (None, None);
+        # the generators that look for one over 65 536 entries cost a millisecond each, five times per call)
+        plain_work = bool(plain)
+        dps = [None] * n if plain_work else [w[1] for w in work]
         live = typed_env(self.env, DomainRandWrapperLive)
-        if any(d is not None for d in dps):
+        if not plain_work and any(d is not None for d in dps):
             mat = np.tile(np.array([base.domain_param[k] for k in v.param_names], dtype=np.float32), (n, 1))
             for j, d in enumerate(dps):
                 if d is not None:
@@ -397,12 +423,13 @@ class ParallelRolloutSampler:
             if ring is not None and ring.buffer:
                 # rollout number r takes set r mod len(buffer) (cyclic) or a random one: the ring of the reference, per lane
                 v.set_param_buffer([ring.buffer] if isinstance(ring.buffer, dict) else ring.buffer, ring.selection)
-        inits = [w[0] for w in work]
+        inits = [None] * n if plain_work else [w[0] for w in work]
+        has_inits = not plain_work and any(s is not None for s in inits)
         v.set_auto_reset(False)
 
         def reset_lanes():  # (a pure function of the seeds and the work list: the graph path calls it a second time)
             v.reset(seed=lane_key)  # init-space sample for every lane ...
-            if any(s is not None for s in inits):  # ... overridden by the explicit init states
+            if has_inits:  # ... overridden by the explicit init states
                 width = {len(np.asarray(s).reshape(-1)) for s in inits if s is not None}
                 if len(width) != 1:
                     raise ValueErr(msg="all init states must have the same shape")
@@ -444,8 +471,12 @@ class ParallelRolloutSampler:
             v.set_record_mode(2 if full else 1)
             v.set_traj_capacity(T_cap)
             launches = 0
+            # steps per launch: `chunk` (128) for short horizons, up to a quarter of the horizon for long ones -- at 4 000 steps a
+            # batch of 65 536 lanes always has a lane that runs to the end, so 32 launches of 128 steps only cost host time
+            # (2 of the 8.6 ms of a 65 536-rollout sample_packed() call); lanes that are done are frozen either way
+            chunk = int(min(max(self._chunk, T_cap // 8), 1024))
             while t < T_cap:
-                k = int(min(self._chunk, T_cap - t))
+                k = int(min(chunk, T_cap - t))
                 v.set_traj_offset(t)
                 v.step_random(k, seed=lane_key ^ 0xA0761D6478BD642F, record=True)
                 t += k
@@ -453,7 +484,7 @@ class ParallelRolloutSampler:
                 # one scalar sync per FOUR launches: a wave whose rollouts have all ended leaves the fused kernel at once, so
                 # up to three launches too many cost next to nothing, a host round trip per launch does (a third of a
                 # 4 096-rollout call)
-                if (launches & 3) == 0 and bool(done_t.bool().all()):
+                if (launches & 3) == 0 and t < T_cap and bool(done_t.bool().all()):
                     break
             v.set_traj_offset(0)
         elif fnn is not None:
@@ -549,29 +580,32 @@ class ParallelRolloutSampler:
         total = int(length.sum())  # the one size-dependent sync
         start = torch.cumsum(length, 0) - length
         pk = v.pack_traj(n, T, length, start, total=total)
-        obs_all = visible(pk["obs"], 1)  # [total + n, O']: one observation more than steps per rollout
-        act_s, rew_s = pk["act"], pk["rew"]
-        # states [T + 1, S] and (qcp) th_ddot [T + 1]: the value before every step and the final one, like observations
-        more = ([pk["state"], pk["act_app"]] + ([pk["hidden"]] if H else [])) if full else []
+        # ONE matrix rows[total + n, F]: rollout j in rows start[j] + j .. start[j] + j + length[j] (its steps, then the entry behind
+        # them: final observation / state / hidden state); every field below is a strided view of it
+        rows = pk["rows"]
+        fields = v.record_fields()
         if packed_out:
-            qcp_dev = base.name.startswith("qcp") and H and bool(more)
+            qcp_dev = base.name.startswith("qcp") and H and full
             return PackedRollouts(
-                observations=obs_all, actions=act_s.contiguous(), rewards=rew_s.contiguous(),
-                states=more[0] if more else None, actions_applied=more[1] if more else None,
-                th_ddot=more[2][:, 0] if qcp_dev else None, lengths=length, offsets=torch.cat([start, start[-1:] + length[-1:]]),
-                done_last=done_last_d, init_states=state0.contiguous(), first_index=first_index,
+                rows=rows, observations=visible(pk["obs"], 1), actions=pk["act"], rewards=pk["rew"],
+                states=pk["state"] if full else None, actions_applied=pk["act_app"] if full else None,
+                th_ddot=pk["hidden"][:, 0] if qcp_dev else None, lengths=length, offsets=torch.cat([start, start[-1:] + length[-1:]]),
+                total=total, done_last=done_last_d, init_states=state0.contiguous(), first_index=first_index,
                 env_name=base.name, dt=base.dt, param_names=v.param_names, domain_params=v.tensor(L.VS_PARAMS)[:, :n].t().clone())
-        # device -> host through pinned staging buffers (a pageable .cpu() of ~70 MB runs at ~3 GB/s here), then one memcpy
-        # each into arrays the caller owns
-        host = self._to_host(
-            [obs_all, act_s.contiguous(), rew_s.contiguous(), done_last_d.to(torch.uint8), length, state0.contiguous()]
-            + more, out_dtypes=[None, None, np.float64] + [None] * (3 + len(more)))  # rewards: one conversion for all rollouts
-        obs_p, act_p, rew_p, done_h, length_h, state0_h = host[:6]
-        st_p, app_p, hid_p = (host[6], host[7], host[8] if H else None) if more else (None, None, None)
+        # device -> host: the matrix in one transfer into pinned memory; the rollouts' fields are views of that block (rewards:
+        # one conversion to float64 for all rollouts)
+        rows_h, done_h, length_h, state0_h = self._to_host([rows, done_last_d.to(torch.uint8), length, state0.contiguous()])
+        c_rew = fields["rew"][0]
+        rew_p = self._convert(rows_h[:, c_rew], np.float64)
+        col = lambda k: rows_h[:, fields[k][0]:fields[k][0] + fields[k][1]]
+        obs_p = col("obs") if keep is None else rows_h[:, np.flatnonzero(self._fc.keep)]
+        act_p = col("act")
+        st_p, app_p = (col("state"), col("act_app")) if full else (None, None)
+        hid_p = col("hidden") if (full and H) else None
         done_last = done_h.astype(bool).tolist()
         params = v.get(L.VS_PARAMS)
-        off = np.concatenate([[0], np.cumsum(length_h)]).tolist()
-        off_o = np.concatenate([[0], np.cumsum(length_h + 1)]).tolist()
+        lens = length_h.tolist()
+        off_o = np.concatenate([[0], np.cumsum(length_h + 1)]).tolist()  # first row of every rollout
         dt, name, pnames = base.dt, base.name, v.param_names
         packed = StepSequence._packed
         qcp = name.startswith("qcp") and hid_p is not None  # the fork's th_ddot field exists for its cartpole only
@@ -580,15 +614,36 @@ class ParallelRolloutSampler:
         gc_was_on = gc.isenabled()
         gc.disable()
         try:
-            ros = [packed(obs_p[off_o[j]:off_o[j + 1]], act_p[off[j]:off[j + 1]], rew_p[off[j]:off[j + 1]],
+            ros = [packed(obs_p[off_o[j]:off_o[j + 1]], act_p[off_o[j]:off_o[j] + lens[j]], rew_p[off_o[j]:off_o[j] + lens[j]],
                           (name, pnames, params[j], first_index + j), done_last[j], dt, state0_h[j],
                           None if st_p is None else st_p[off_o[j]:off_o[j + 1]],
-                          None if app_p is None else app_p[off[j]:off[j + 1]],
+                          None if app_p is None else app_p[off_o[j]:off_o[j] + lens[j]],
                           hid_p[off_o[j]:off_o[j + 1], 0] if qcp else None) for j in range(n)]
         finally:
             if gc_was_on:
                 gc.enable()
         return ros
+
+    def _convert(self, src, dtype):
+        """a (possibly strided) host array as a dense array of another dtype, in chunks on a few threads (NumPy releases the GIL)"""
+        dst = np.empty(src.shape, dtype=dtype)
+        rows = src.shape[0] if src.ndim else 0
+        chunk_rows = 1 << 20
+        if rows <= chunk_rows:
+            np.copyto(dst, src, casting="unsafe")
+            return dst
+        pool = self._pool()
+        jobs = [pool.submit(np.copyto, dst[a:a + chunk_rows], src[a:a + chunk_rows], "unsafe") for a in range(0, rows, chunk_rows)]
+        for j in jobs:
+            j.result()
+        return dst
+
+    def _pool(self):
+        if not hasattr(self, "_copy_pool"):
+            from concurrent.futures import ThreadPoolExecutor
+
+            self._copy_pool = ThreadPoolExecutor(max_workers=max(1, min(8, len(os.sched_getaffinity(0)))))
+        return self._copy_pool
 
     def _to_host(self, tensors, out_dtypes=None):
         """device tensors as NumPy arrays the caller owns.  Every tensor goes into a FRESH pinned host tensor (a pageable .cpu()
@@ -600,10 +655,7 @@ class ParallelRolloutSampler:
         (NumPy releases the GIL), as soon as that tensor's own transfer has landed."""
         import torch
 
-        if not hasattr(self, "_copy_pool"):
-            from concurrent.futures import ThreadPoolExecutor
-
-            self._copy_pool = ThreadPoolExecutor(max_workers=max(1, min(8, len(os.sched_getaffinity(0)))))
+        self._pool()
         stream = torch.cuda.current_stream(tensors[0].device)
         staged = []
         for t in tensors:
@@ -642,7 +694,7 @@ class ParallelRolloutSampler:
             work = self.work_list(init_states, domain_params)
             out = []
             for a in range(0, len(work), self._batch_lanes):
-                out += self._run_batch(work[a:a + self._batch_lanes], a, eval)
+                out += self._run_batch(work[a:a + self._batch_lanes], a, eval, plain=init_states is None and domain_params is None)
             return out
         if init_states is not None:
             raise NotImplementedError  # as in the reference (parallel_rollout_sampler.py:315-316)
@@ -651,7 +703,7 @@ class ParallelRolloutSampler:
         guess = max(self.min_rollouts or 1, 1)
         while True:
             nb = int(min(self._batch_lanes, max(guess, 64)))
-            batch = self._run_batch([(None, None)] * nb, idx, eval)
+            batch = self._run_batch([_PLAIN_WORK] * nb, idx, eval, plain=True)
             for ro in batch:
                 out.append(ro)
                 steps += len(ro)
@@ -670,7 +722,8 @@ class ParallelRolloutSampler:
             raise ValueErr(msg="sample_packed() runs a fixed number of rollouts: construct the sampler with min_rollouts")
         self._sample_count += 1
         work = self.work_list(init_states, domain_params)
-        return [self._run_batch(work[a:a + self._batch_lanes], a, eval, packed_out=True)
+        return [self._run_batch(work[a:a + self._batch_lanes], a, eval, packed_out=True,
+                                plain=init_states is None and domain_params is None)
                 for a in range(0, len(work), self._batch_lanes)]
 
 

@@ -493,24 +493,23 @@ class VecSimEnv:
         return lengths, done_last.bool()
 
     def pack_traj(self, n, t_steps, lengths, starts, total=None):
-        """vs_pack_traj: rollout j = the first lengths[j] recorded steps of lane j (j < n), packed one after the other on the
-        device (lengths / starts: int64 device tensors, starts the exclusive cumulative sum).  Returns dict(obs [total + n, O],
-        act [total, A], rew [total]; record mode 2: state [total + n, S], act_app [total, A], hidden [total + n, H] | None)"""
+        """vs_pack_traj: rollout j = the first lengths[j] recorded steps of lane j (j < n), the rollouts one after the other in ONE
+        matrix on the device (lengths / starts: int64 device tensors, starts the exclusive cumulative sum): `rows` [total + n, F],
+        rollout j in rows starts[j] + j .. starts[j] + j + lengths[j] -- its steps and, last, the entry behind them (final
+        observation / state / hidden state).  Returns dict(rows=..., obs, act, rew; record mode 2: state, act_app, hidden | None):
+        the fields are strided VIEWS of `rows` ([total + n, width]; rew [total + n]), all indexed by the same rows."""
         import torch
 
         total = int(starts[-1] + lengths[-1]) if total is None else int(total)  # (a device sync unless the caller knows it)
         dev = lengths.device
-        O, A, S, H = self.dims["O"], self.dims["A"], self.dims["S"], self.dims["H"]
-        full = self.record_mode == 2
-        out = dict(obs=torch.empty(total + n, O, device=dev), act=torch.empty(total, A, device=dev), rew=torch.empty(total, device=dev))
-        if full:
-            out.update(state=torch.empty(total + n, S, device=dev), act_app=torch.empty(total, A, device=dev),
-                       hidden=torch.empty(total + n, H, device=dev) if H else None)
-        ptr = lambda k: C.c_void_p(out[k].data_ptr()) if out.get(k) is not None else None
+        F = self.traj_layout()[0]
+        rows = torch.empty(total + n, F, device=dev)
         lengths, starts = lengths.to(torch.int64).contiguous(), starts.to(torch.int64).contiguous()
         self._check(self._lib.vs_pack_traj(self._h, int(n), int(t_steps), C.c_void_p(lengths.data_ptr()), C.c_void_p(starts.data_ptr()),
-                                           ptr("obs"), ptr("act"), ptr("rew"), ptr("state"), ptr("act_app"), ptr("hidden")),
-                    "vs_pack_traj")
+                                           C.c_void_p(rows.data_ptr())), "vs_pack_traj")
+        out = dict(rows=rows)
+        for k, (c0, w) in self.record_fields().items():
+            out[k] = None if w == 0 else (rows[:, c0] if k == "rew" else rows[:, c0:c0 + w])
         return out
 
     def traj_tensors(self, k_steps=None, n=None):

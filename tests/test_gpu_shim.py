@@ -585,6 +585,9 @@ def test_sample_packed_holds_what_sample_returns(vs, name, policy_kind):
     for p in packs:
         assert p.first_index == j0 and p.observations.is_cuda and p.offsets.shape == (len(p) + 1,)
         assert p.total_steps == int(p.lengths.sum()) == int(p.offsets[-1])
+        assert p.rows.shape[0] == p.total_steps + len(p) and p.actions.shape[0] == p.rows.shape[0]  # fields: views of one matrix
+        dense_act = p.actions[p.step_rows()]  # the reference-style concatenation (StepSequence.concat drops the final entries)
+        assert dense_act.shape[0] == p.total_steps
         ret = p.undiscounted_returns().cpu().numpy()
         for j in range(len(p)):
             ro = ros[j0 + j]
@@ -647,15 +650,23 @@ def test_pack_traj_kernel_equals_the_index_gather(vs, name, mode):
     t_idx = torch.arange(total, device=lane.device) - start[lane]
     fin = {"obs": e.tensor(L.VS_OBS)[:, :n].t(), "state": e.tensor(L.VS_STATE)[:, :n].t(),
            "hidden": e.tensor(L.VS_HIDDEN)[:, :n].t() if e.dims["H"] else None}
+    # one matrix rows[total + n, F]: step t of rollout j in row start[j] + j + t, the entry behind the last step in row
+    # start[j] + j + length[j] (final observation / state / hidden state, per-step fields 0); the fields are views of it
+    F = e.traj_layout()[0]
+    assert pk["rows"].shape == (total + n, F) and pk["rows"].is_contiguous()
+    step_row = torch.arange(total, device=lane.device) + lane
+    fin_row = start + length + ar
     for key in ("act", "rew") + (("act_app",) if mode == 2 else ()):
-        assert torch.equal(pk[key], tt[key][t_idx, lane]), key
+        assert pk[key].shape[0] == total + n and pk[key].data_ptr() >= pk["rows"].data_ptr()  # (a view)
+        assert torch.equal(pk[key][step_row], tt[key][t_idx, lane]), key
+        assert float(pk[key][fin_row].abs().max()) == 0.0, key
     for key in ("obs",) + (("state", "hidden") if mode == 2 else ()):
         if key == "hidden" and not e.dims["H"]:
             assert pk[key] is None
             continue
         want = torch.empty(total + n, tt[key].shape[2], device=lane.device)
-        want[torch.arange(total, device=lane.device) + lane] = tt[key][t_idx, lane]
-        want[start + length + ar] = fin[key]
+        want[step_row] = tt[key][t_idx, lane]
+        want[fin_row] = fin[key]
         assert torch.equal(pk[key], want), key
     if mode == 1:
         assert "state" not in pk
