@@ -520,7 +520,8 @@ struct QcpT : EnvDefaults<1> {
     static constexpr int S = 4, A = 1, O = 5, H = 1, I = 4, P = 17, K = 16, KS = 16;
     static constexpr int REW = V == 1 ? REW_QUADR : REW_EXP, RADIAL = 1, CMAX = -1;
     static constexpr bool REWARD_SIDE_USES_CONSTS = false;
-    static constexpr int WS_SHAPE_FULL = 256;
+    // (64-env workgroups at 65 536 envs since round 3: with the physics wave issuing first (s_setprio) 247.8 against 255.9 us per
+    // 400 recorded steps in 256-env workgroups -- the inherited default; round 2 had measured the two the other way round)
     static constexpr bool WS_MID = false;
     static constexpr int WS_PREP_C = 1;  // a chain of four dependent _dynamics evaluations: every instruction off it counts
     static constexpr int WS_MIN_WAVES = 2;  // 65 536 envs in 64-env workgroups are two waves per SIMD: at most 256 VGPRs

@@ -330,12 +330,16 @@ __device__ __forceinline__ void draw_params(const DrSpecs* dr, Rng& g, float* p)
     }
 }
 
+// lds_params (k_rollout_ws under a live randomizer): the lane's parameter rows in LDS, [P][lds_pitch] -- the rows a redraw does
+// not touch are the same there as in VS_PARAMS, the randomised ones are overwritten by the draws below whatever they hold: the
+// redraw then starts without waiting for P global loads (~3 000 cycles on the wave that runs it for one or two of its lanes)
 template <class E>
 __device__ __forceinline__ void redraw_lane_params(const Task& T, const Dev& d, const DrSpecs* dr, int i, uint64_t seed,
-                                                   uint64_t epi, float* c) {
+                                                   uint64_t epi, float* c, const float* lds_params = nullptr, int lds_pitch = 0,
+                                                   int lds_lane = 0) {
     float p[E::P];
 #pragma unroll
-    for (int k = 0; k < E::P; ++k) p[k] = d.params[(size_t)k * d.ld + i];
+    for (int k = 0; k < E::P; ++k) p[k] = lds_params ? lds_params[k * lds_pitch + lds_lane] : d.params[(size_t)k * d.ld + i];
     Rng gp(seed, d.idx0 + (uint32_t)i, RNG_PARAM, epi);
     draw_params<E>(dr, gp, p);
     E::calc_consts(T, p, c);
@@ -351,8 +355,9 @@ __device__ __forceinline__ void redraw_lane_params(const Task& T, const Dev& d, 
 // steps are chunked into launches and of hipGraph replay.
 template <class E>
 __device__ __forceinline__ void reset_lane_sampled(const Task& T, const Dev& d, bool with_dr, int i, uint64_t seed,
-                                                   uint64_t epi, float* c, float* s, float* h) {
-    if (with_dr && d.dr_n > 0) redraw_lane_params<E>(T, d, &d.drv, i, seed, epi, c);
+                                                   uint64_t epi, float* c, float* s, float* h,
+                                                   const float* lds_params = nullptr, int lds_pitch = 0, int lds_lane = 0) {
+    if (with_dr && d.dr_n > 0) redraw_lane_params<E>(T, d, &d.drv, i, seed, epi, c, lds_params, lds_pitch, lds_lane);
     if (with_dr && d.pbuf_n > 0) {
         // DomainRandWrapperBuffer.reset (domain_randomization.py:236-251): next set of the ring, or a random one
         uint32_t k;
@@ -1559,6 +1564,9 @@ __attribute__((amdgpu_waves_per_eu(NR == 3 ? 3 : E::WS_MIN_WAVES, (NE == 64 && N
 
     if (role == 0) {
         // ------------------------------------------------------------------------------------------- P wave
+        // the long wave of most families and the one the others wait for at the barrier: it issues first where it shares a SIMD
+        // (measured: BASELINE config 3 + 6 %, every other shape within +- 1 %)
+        __builtin_amdgcn_s_setprio(3);
         float s[E::S], h[NH], tr[NT], ob[E::O];
 #pragma unroll
         for (int j = 0; j < E::S; ++j) s[j] = d.state[j * ld + i];
@@ -1684,7 +1692,8 @@ __attribute__((amdgpu_waves_per_eu(NR == 3 ? 3 : E::WS_MIN_WAVES, (NE == 64 && N
                             if (!stocked) {
                                 // live domain randomisation redraws the lane's parameters here: allowed for the families
                                 // whose C wave does not read constants (use_ws)
-                                reset_lane_sampled<E>(T, d, !UNI, i, reset_seed, (uint64_t)epi, c, s, h);
+                                reset_lane_sampled<E>(T, d, !UNI, i, reset_seed, (uint64_t)epi, c, s, h,
+                                                      dr_stock ? (const float*)l_npar : (const float*)nullptr, NE, le);
                                 if (REC) E::observe_p(s, tr);
                             }
                             epi += 1u;
