@@ -119,13 +119,20 @@ __device__ __forceinline__ float rcp_fast(float x) {
     return fmaf(fmaf(-x, r, 1.0f), r, r);
 }
 
+// 1/x by the hardware approximation alone (1 ulp); Dual: through rcp_fast
+__device__ __forceinline__ float rcp_det(float x) { return __builtin_amdgcn_rcpf(x); }
+template <int N>
+__device__ __forceinline__ Dual<N> rcp_det(const Dual<N>& x);  // (defined behind rcp_fast<Dual>)
+
 // sin and cos of a0 + dl from (sin a0, cos a0) by the addition theorems, for a SMALL increment dl (|dl| <~ 0.5: the stage
 // angles of an RK step are the step's angle plus dt/2 or dt times a rate).  Truncation error of the two series below
-// |dl|^9 / 9! and |dl|^8 / 8! (< 1e-8 at 0.5); 12 instructions against the 28 of a fresh range reduction + polynomials.
+// |dl|^7 / 7! (sine: 1.6e-8 at the 0.26 rad the cartpole's dt <= 4 ms branch allows) and |dl|^8 / 8! (cosine); 11 instructions
+// against the 28 of a fresh range reduction + polynomials.
 template <class R>
 __device__ __forceinline__ void sincos_rot(const R& s0, const R& c0, const R& dl, R* sn, R* cs) {
     R d2 = dl * dl;
-    R sd = dl + dl * d2 * (-1.6666667163e-1f + d2 * (8.3333337680e-3f + d2 * -1.9841270114e-4f));
+    // (sine to dl^5: the dl^7 term is below 7e-8 of sin(dl) for |dl| <= 0.26 -- an ulp -- and was one more instruction per stage)
+    R sd = dl + dl * d2 * (-1.6666667163e-1f + d2 * 8.3333337680e-3f);
     R cd = 1.0f + d2 * (-0.5f + d2 * (4.1666667908e-2f + d2 * -1.3888889225e-3f));
     *sn = s0 * cd + c0 * sd;
     *cs = c0 * cd - s0 * sd;
@@ -151,6 +158,8 @@ __device__ __forceinline__ Dual<N> rcp_fast(const Dual<N>& x) {
     for (int k = 0; k < N; ++k) r.d[k] = -r.v * r.v * x.d[k];
     return r;
 }
+template <int N>
+__device__ __forceinline__ Dual<N> rcp_det(const Dual<N>& x) { return rcp_fast(x); }
 
 __device__ __forceinline__ float sgnf(float x) { return (float)(x > 0.f) - (float)(x < 0.f); }  // np.sign
 
@@ -574,7 +583,19 @@ struct QcpT : EnvDefaults<1> {
         if (!simple && c[C_TH_NEG] <= u && u <= c[C_TH_POS]) u = 0.f;  // dead zone :188-192
         R f_act = c[C_KA] * (c[C_ETA_M] * u - c[C_KB] * x_dot);
         R f_tot = f_act;
-        if (!simple) {
+        // Coulomb friction :199-208, f_c = 0 if f_normal < 0 else mu_c f_normal sign(x_dot).  This function is evaluated four times
+        // per step on the ONE wave the cartpole's kernels wait for (~270 dependent vector instructions per step):
+        // every instruction here counts four times.  Round 3 (float path; the Jacobian kernel's Dual path keeps the plain form):
+        // the product with sign(x_dot) as a sign-bit flip, zero where x_dot == 0 or f_normal < 0 (exactly v * np.sign(x): - 3
+        // instructions), and the whole term computed unconditionally and dropped by a select for simple_dynamics (a wave-uniform
+        // branch per stage cut the step into eight basic blocks)
+        if constexpr (std::is_same<R, float>::value) {
+            float f_normal = c[C_MTG] - c[C_MPL2] * (sin_th * thdd_prev + cos_th * th_dot * th_dot);
+            float t = c[C_MU] * f_normal;
+            float f_c = __uint_as_float(__float_as_uint(t) ^ (__float_as_uint(x_dot) & 0x80000000u));  // t * sign(x_dot), x_dot != 0
+            f_c = (f_normal < 0.f || x_dot == 0.f) ? 0.f : f_c;
+            f_tot = simple ? f_act : f_act - f_c;
+        } else if (!simple) {
             R f_normal = c[C_MTG] - c[C_MPL2] * (sin_th * thdd_prev + cos_th * th_dot * th_dot);
             R f_c = vsel(f_normal < 0.f, R(0.f), c[C_MU] * f_normal * sgnf(val(x_dot)));
             f_tot = f_act - f_c;
@@ -582,8 +603,9 @@ struct QcpT : EnvDefaults<1> {
         R M01 = c[C_MPL] * cos_th;
         R r0 = f_tot - c[C_BEQ] * x_dot - c[C_MPL] * sin_th * th_dot * th_dot;
         R r1 = -c[C_BP] * th_dot - c[C_MPLG] * sin_th;
-        // np.linalg.solve on the SPD 2x2 -> closed form
-        R inv_det = rcp_fast(c[C_M00] * c[C_M11] - M01 * M01);
+        // np.linalg.solve on the SPD 2x2 -> closed form; the determinant's reciprocal by the bare v_rcp_f32 (1 ulp: the Newton step
+        // of rcp_fast was two more instructions per stage for the last half ulp of an fp32 result compared at 1e-5)
+        R inv_det = rcp_det(c[C_M00] * c[C_M11] - M01 * M01);
         R x_ddot = (c[C_M11] * r0 - M01 * r1) * inv_det;
         R th_ddot = (c[C_M00] * r1 - M01 * r0) * inv_det;
         k[0] = x_dot + x_ddot * T.dt;  // already Euler-advanced velocities as position derivative (Q6, :227-230)
