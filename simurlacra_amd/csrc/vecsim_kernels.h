@@ -414,7 +414,9 @@ struct EpStat {
 
 // auto-reset of the lanes of a wave that finished an episode (wave-uniform early out: most waves have none).
 // No memory traffic unless live domain randomisation rewrites the lane's params/constants or the episode log is on.
-template <class E, bool UNI>
+// DRK: the redraw of a live randomizer / parameter buffer is compiled in (see k_rollout_ws); the kernels of a handle that has
+// neither carry none of it
+template <class E, bool UNI, bool DRK = !UNI>
 __device__ __forceinline__ void auto_reset(const Task& T, const Dev& d, bool fin, int i, uint64_t seed, float* c,
                                            float* s, float* h, int& step, float& ret, bool& yielded, EpStat& es) {
     if (__builtin_amdgcn_ballot_w64(fin) == 0ull) return;
@@ -425,7 +427,7 @@ __device__ __forceinline__ void auto_reset(const Task& T, const Dev& d, bool fin
         es.retsum += ret;
         es.lensum += step;
         load_consts<E, UNI>(d, i, c, E::KS, E::K);  // reset-only constants
-        reset_lane_sampled<E>(T, d, !UNI, i, seed, (uint64_t)es.epi, c, s, h);
+        reset_lane_sampled<E>(T, d, DRK, i, seed, (uint64_t)es.epi, c, s, h);
         es.epi += 1u;
         step = 0;
         ret = 0.f;
@@ -562,7 +564,7 @@ __device__ __forceinline__ void applied_action(const Task& T, const float* c, co
 // action, the reward, and in mode 2 the state and hidden state before the step and env.limit_act(act) -- into row `row` of
 // the VS_TRAJ_* buffers, or, for row < 0, into the row the handle's device-side counter names (Dev::rec_row: a captured
 // hipGraph replays with the counter advanced by k_bump_row between the steps).  Rows beyond the capacity are not written.
-template <class E, bool UNI, bool AR, bool PIPE = false, int REC = 0>
+template <class E, bool UNI, bool AR, bool PIPE = false, int REC = 0, bool DRK = !UNI>
 __device__ __forceinline__ void step_body(const Task& T, const Dev& d, const float* __restrict__ act, long env_stride,
                                           long dim_stride, uint64_t seed, int block, int row = 0) {
     int i = block * BLOCK + threadIdx.x;
@@ -630,7 +632,7 @@ __device__ __forceinline__ void step_body(const Task& T, const Dev& d, const flo
         if (__builtin_amdgcn_ballot_w64(fin) != 0ull) {  // single-step kernel: the per-env counters are touched by finishing lanes only
             EpStat es{0u, 0u, 0.f, 0};
             if (fin) es = EpStat{d.ep_idx[i], d.es_count[i], d.es_retsum[i], d.es_lensum[i]};
-            auto_reset<E, UNI>(T, d, fin, i, seed, c, s, h, step, ret, yielded, es);
+            auto_reset<E, UNI, DRK>(T, d, fin, i, seed, c, s, h, step, ret, yielded, es);
             if (fin) {
                 d.ep_idx[i] = es.epi;
                 d.es_count[i] = es.count;
@@ -657,10 +659,10 @@ __device__ __forceinline__ void step_body(const Task& T, const Dev& d, const flo
     if (E::FINAL != FINAL_NONE) d.yielded[i] = yielded;
 }
 
-template <class E, bool UNI, bool AR, bool PIPE, int REC>
+template <class E, bool UNI, bool AR, bool PIPE, int REC, bool DRK = false>
 __global__ __launch_bounds__(BLOCK) void k_step(Task T, Dev d, const float* __restrict__ act, long env_stride,
                                                 long dim_stride, uint64_t seed, int row) {
-    step_body<E, UNI, AR, PIPE, REC>(T, d, act, env_stride, dim_stride, seed, (int)blockIdx.x, row);
+    step_body<E, UNI, AR, PIPE, REC, DRK>(T, d, act, env_stride, dim_stride, seed, (int)blockIdx.x, row);
 }
 
 // ---------------------------------------------------------------------------------------------------- Jacobian kernel
@@ -742,7 +744,7 @@ __global__ __launch_bounds__(BLOCK) void k_step_jac(Task T, Dev d, const float* 
 // Without auto-reset a finished lane freezes (rollout stops at done).
 // Actions: Philox4x32-10 keyed by `seed`, counter (env, RNG_ACT, absolute step / SPB); one block feeds SPB = 4 / A
 // consecutive steps (the block boundary is wave-uniform because it depends on the launch-global step index only).
-template <class E, bool UNI, bool AR, int REC, bool PIPE = false>
+template <class E, bool UNI, bool AR, int REC, bool PIPE = false, bool DRK = !UNI>
 __device__ __forceinline__ void rollout_body(const Task& T, const Dev& d, int k_steps, uint64_t seed, uint64_t reset_seed,
                                              uint64_t epoch0, int block) {
     const size_t rec0 = (size_t)d.traj_t0;  // first record row of this launch (vs_set_traj_offset)
@@ -827,7 +829,7 @@ __device__ __forceinline__ void rollout_body(const Task& T, const Dev& d, int k_
         }
         bool fin = done && valid && !frozen;
         if (AR) {
-            auto_reset<E, UNI>(T, d, fin, i, reset_seed, c, s, h, step, ret, yielded, es);
+            auto_reset<E, UNI, DRK>(T, d, fin, i, reset_seed, c, s, h, step, ret, yielded, es);
             if (!UNI) E::act_bounds(c, alo, ahi);  // the action space may depend on redrawn params (omo, bob)
         } else {
             if (fin) {  // rollout() ends here for this lane: book the episode once, then freeze
@@ -868,10 +870,10 @@ __device__ __forceinline__ void rollout_body(const Task& T, const Dev& d, int k_
     d.es_lensum[i] = es.lensum;
 }
 
-template <class E, bool UNI, bool AR, int REC, bool PIPE>
+template <class E, bool UNI, bool AR, int REC, bool PIPE, bool DRK = false>
 __global__ __launch_bounds__(BLOCK) void k_rollout(Task T, Dev d, int k_steps, uint64_t seed, uint64_t reset_seed,
                                                    uint64_t epoch0) {
-    rollout_body<E, UNI, AR, REC, PIPE>(T, d, k_steps, seed, reset_seed, epoch0, (int)blockIdx.x);
+    rollout_body<E, UNI, AR, REC, PIPE, DRK>(T, d, k_steps, seed, reset_seed, epoch0, (int)blockIdx.x);
 }
 
 // LDS-only workgroup barrier of the multi-wave kernels below
@@ -1382,10 +1384,15 @@ __global__ __launch_bounds__(64 * fnn_waves(NHID)) void k_rollout_fnn(Task T, De
 // padded to 257 VGPRs): its physics wave is by far the long one and loses 15 % when the hardware, free to do so since the
 // kernel needs only 136 registers, puts both waves of a workgroup on one SIMD and leaves another idle
 // (scratch/ubench/place2.hip: 512 workgroups of 128 threads land as [PC][--][P-][-C] per compute unit, [P][C][P][C] when padded).
-template <class E, bool UNI, bool AR, int REC, int WS_R, int NE, bool DP, int NR = 2>
+// DRK ("domain randomisation compiled in"): the handle has a live randomizer or a parameter buffer, i.e. a reset inside the
+// launch redraws the lane's domain parameters.  The kernels without it (the headline's, every nominal-parameter batch) carry
+// none of that code -- the redraw (Philox, Box-Muller, the parameter select chains, _calc_constants) was ~1 000 instructions in
+// each of the eight inlined reset blocks of a kernel that never executes it.
+template <class E, bool UNI, bool AR, int REC, int WS_R, int NE, bool DP, int NR = 2, bool DRK = false>
 __global__ __launch_bounds__(NR * NE)
 __attribute__((amdgpu_waves_per_eu(NR == 3 ? 3 : E::WS_MIN_WAVES, (NE == 64 && NR == 2 && E::WS_ALONE) ? 1 : 0))) void k_rollout_ws(Task T, Dev d, int k_steps, uint64_t seed, uint64_t reset_seed,
                                                         uint64_t epoch0) {
+    static_assert(!DRK || (!UNI && AR), "a randomizer needs per-env constants and resets inside the launch");
     static_assert(E::FINAL != FINAL_STATE_TIME, "needs the post-step state on the reward side");
     static_assert(NE == 64 || NE == 128 || NE == 256, "envs per workgroup");
     static_assert(NR == 2 || (NR == 3 && !DP), "two roles, or three with the generator wave drawing the actions");
@@ -1438,8 +1445,8 @@ __attribute__((amdgpu_waves_per_eu(NR == 3 ? 3 : E::WS_MIN_WAVES, (NE == 64 && N
     //   [P][NE] the parameters of the entry (a redraw overwrites the randomised ones in place; the others are the lane's
     //   parameters at the start of the launch and never change) | [K][NE] the constants calc_consts derives from them
     extern __shared__ float l_dyn[];
-    const bool dr_stock = STOCK && !UNI && d.dr_n > 0 && d.pbuf_n == 0;            // wave-uniform
-    const bool stock_on = STOCK && d.pbuf_n == 0 && (d.dr_n == 0 || dr_stock);     // wave-uniform
+    const bool dr_stock = DRK && STOCK && !UNI && d.dr_n > 0 && d.pbuf_n == 0;     // wave-uniform (false at compile time without DRK)
+    const bool stock_on = STOCK && (!DRK || (d.pbuf_n == 0 && (d.dr_n == 0 || dr_stock)));  // wave-uniform
     float* const l_npar = l_dyn;
     float* const l_ncon = l_dyn + E::P * NE;
     const int wave = threadIdx.x >> 6;
@@ -1692,7 +1699,7 @@ __attribute__((amdgpu_waves_per_eu(NR == 3 ? 3 : E::WS_MIN_WAVES, (NE == 64 && N
                             if (!stocked) {
                                 // live domain randomisation redraws the lane's parameters here: allowed for the families
                                 // whose C wave does not read constants (use_ws)
-                                reset_lane_sampled<E>(T, d, !UNI, i, reset_seed, (uint64_t)epi, c, s, h,
+                                reset_lane_sampled<E>(T, d, DRK, i, reset_seed, (uint64_t)epi, c, s, h,
                                                       dr_stock ? (const float*)l_npar : (const float*)nullptr, NE, le);
                                 if (REC) E::observe_p(s, tr);
                             }
@@ -2342,11 +2349,12 @@ template <class E, int REC>
 static void launch_step_rec(vs_env* h, const float* act, long es, long ds, int row) {
     dim3 g = grid_for(h->d.ld), b(BLOCK);
     bool uni = h->uniform && h->dr.n == 0 && h->d.pbuf_n == 0;
-#define LS(U, AR, PI) hipLaunchKernelGGL((k_step<E, U, AR, PI, REC>), g, b, 0, h->stream, h->task, h->d, act, es, ds, h->ar_seed, row)
+    const bool drk = h->d.dr_n > 0 || h->d.pbuf_n > 0;  // a reset inside the launch redraws domain parameters
+#define LS(U, AR, PI, DK) hipLaunchKernelGGL((k_step<E, U, AR, PI, REC, DK>), g, b, 0, h->stream, h->task, h->d, act, es, ds, h->ar_seed, row)
     if (h->d.pipe.act_on || h->d.pipe.obs_on) {  // the wrapper pipeline: per-env-constant variant only
-        if (h->auto_reset) LS(false, true, true); else LS(false, false, true);
-    } else if (h->auto_reset) { if (uni) LS(true, true, false); else LS(false, true, false); }
-    else { if (uni) LS(true, false, false); else LS(false, false, false); }
+        if (h->auto_reset) { if (drk) LS(false, true, true, true); else LS(false, true, true, false); } else LS(false, false, true, false);
+    } else if (h->auto_reset) { if (uni) LS(true, true, false, false); else if (drk) LS(false, true, false, true); else LS(false, true, false, false); }
+    else { if (uni) LS(true, false, false, false); else LS(false, false, false, false); }
 #undef LS
 }
 
@@ -2363,10 +2371,12 @@ static void launch_ws(vs_env* h, int k, uint64_t seed, uint64_t ep, int rec) {
         dim3 g((unsigned)(h->d.ld / NE)), b(NR * NE);
         // dynamic LDS: the live randomizer's part of the reset stock (see the kernel), only when one is set
         const unsigned dyn = (!U && AR && h->d.dr_n > 0 && h->d.pbuf_n == 0) ? (unsigned)((E::P + E::K) * NE * sizeof(float)) : 0u;
+        // the instantiation with the redraw compiled in only for a handle that has a randomizer or a parameter buffer
+        const bool drk = !U && AR && (h->d.dr_n > 0 || h->d.pbuf_n > 0);
         // R = 4 steps per exchange (measured on the headline config: R = 1 / 2 / 4 -> 68.7 / 64.8 / 62.0 us per 100 steps)
-#define LW(REC)                                                                                                            \
+#define LWK(REC, DRKV)                                                                                                     \
     {                                                                                                                      \
-        auto kern = k_rollout_ws<E, U, AR, REC, 4, NE, (NR == 2 && E::WS_DRAW_P && REC != 0), NR>;                          \
+        auto kern = k_rollout_ws<E, U, AR, REC, 4, NE, (NR == 2 && E::WS_DRAW_P && REC != 0), NR, DRKV>;                    \
         static unsigned char attr_set[64] = {}; /* once per kernel and device */                                           \
         if (dyn && !attr_set[h->device & 63]) {                                                                            \
             (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);            \
@@ -2374,17 +2384,26 @@ static void launch_ws(vs_env* h, int k, uint64_t seed, uint64_t ep, int rec) {
         }                                                                                                                  \
         hipLaunchKernelGGL(kern, g, b, dyn, h->stream, h->task, h->d, k, seed, h->ar_seed, ep);                            \
     }
+#define LW(REC)                                                                                                            \
+    {                                                                                                                      \
+        if constexpr (!U && AR) { if (drk) LWK(REC, true) else LWK(REC, false) }                                            \
+        else LWK(REC, false)                                                                                               \
+    }
         if (rec == 0) LW(0) else if (rec == 1) LW(1) else LW(2)
 #undef LW
+#undef LWK
     }
 }
 
 template <class E, bool U, bool AR, bool PI>
 static void launch_plain(vs_env* h, int k, uint64_t seed, uint64_t ep, int rec) {
     dim3 g = grid_for(h->d.ld), b(BLOCK);
-#define LR(REC) hipLaunchKernelGGL((k_rollout<E, U, AR, REC, PI>), g, b, 0, h->stream, h->task, h->d, k, seed, h->ar_seed, ep)
-    if (rec == 0) LR(0); else if (rec == 1) LR(1); else LR(2);
+    const bool drk = h->d.dr_n > 0 || h->d.pbuf_n > 0;  // a reset inside the launch redraws domain parameters
+#define LRK(REC, DK) hipLaunchKernelGGL((k_rollout<E, U, AR, REC, PI, DK>), g, b, 0, h->stream, h->task, h->d, k, seed, h->ar_seed, ep)
+#define LR(REC) { if constexpr (!U && AR) { if (drk) LRK(REC, true); else LRK(REC, false); } else LRK(REC, false); }
+    if (rec == 0) LR(0) else if (rec == 1) LR(1) else LR(2)
 #undef LR
+#undef LRK
 }
 
 template <class E>
