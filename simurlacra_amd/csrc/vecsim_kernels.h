@@ -1588,22 +1588,9 @@ __attribute__((amdgpu_waves_per_eu(NR == 3 ? 3 : E::WS_MIN_WAVES, (NE == 64 && N
         if (DP) carry = Rng::philox(seed, d.idx0 + (uint32_t)i, RNG_ACT, blk0);
         __builtin_amdgcn_s_waitcnt(0x0F70);
         ws_barrier();  // the actions of batch 0 are in l_act[0] (!DP)
-        // one batch of the P side; FULL: all WS_R steps exist (every batch but a ragged last one) -- no step guards, so that the
-        // unrolled steps form as few basic blocks as the rare reset branch allows
-        auto p_batch = [&](auto full_tag, int b, int nr) __attribute__((always_inline)) {
-            constexpr bool FULL = decltype(full_tag)::value;
-            // all actions of the batch up front: one LDS round trip per batch instead of one per step on the critical path
-            float a_all[WS_R][AW];
-            if (DP) {
-                draw_batch(b, a_all);
-            } else {
-#pragma unroll
-                for (int r = 0; r < WS_R; ++r) Planes<AW>::load(l_act[ab(b)][DP ? 0 : r], NE, le, a_all[r]);
-            }
-#pragma unroll
-            for (int r = 0; r < WS_R; ++r) {
-                if (!FULL && r >= nr) continue;
-                const float* a = a_all[r];
+        // one step of the P side: a = the step's action(s) as l_act / draw_batch hands them over, msg = its row of l_msg
+        auto p_step = [&](const float* a, float* msg) __attribute__((always_inline)) {
+            {
                 float v[M];
 #pragma unroll
                 for (int j = 0; j < E::S; ++j) v[j] = s[j];
@@ -1659,7 +1646,7 @@ __attribute__((amdgpu_waves_per_eu(NR == 3 ? 3 : E::WS_MIN_WAVES, (NE == 64 && N
                               (!AR && frozen ? WSF_FROZEN : 0u);  // fin = done & !frozen & valid is recomputed by C
                 v[M0 - 1] = __uint_as_float(fl);
                 if (M > M0) v[M - 1] = 0.f;
-                Planes<M>::store(l_msg[b & 1][r], NE, le, v);
+                Planes<M>::store(msg, NE, le, v);
                 if (AR) {
                     if (__builtin_amdgcn_ballot_w64(fin) != 0ull) {
                         VS_STAMP(sr0);
@@ -1723,6 +1710,41 @@ __attribute__((amdgpu_waves_per_eu(NR == 3 ? 3 : E::WS_MIN_WAVES, (NE == 64 && N
                 }
             }
         };
+        // A full batch: all WS_R steps exist -- the actions of the batch up front (one LDS round trip per batch instead of one per
+        // step on the critical path), the steps unrolled: as few basic blocks as the rare reset branch allows.
+        auto p_batch_full = [&](int b) __attribute__((always_inline)) {
+            float a_all[WS_R][AW];
+            if (DP) {
+                draw_batch(b, a_all);
+            } else {
+#pragma unroll
+                for (int r = 0; r < WS_R; ++r) Planes<AW>::load(l_act[ab(b)][DP ? 0 : r], NE, le, a_all[r]);
+            }
+#pragma unroll
+            for (int r = 0; r < WS_R; ++r) p_step(a_all[r], l_msg[b & 1][r]);
+        };
+        // The ragged last batch of a launch whose step count is not a multiple of WS_R: ONE rolled copy of the step (round 2 kept a
+        // second, guarded copy of the unrolled batch: with its four inlined reset blocks it doubled the code of this wave's loop
+        // for a batch that runs at most once per launch)
+        auto p_batch_ragged = [&](int b, int nr) __attribute__((always_inline)) {
+            float a_all[WS_R][AW];
+            if (DP) draw_batch(b, a_all);
+#pragma unroll 1
+            for (int r = 0; r < nr; ++r) {
+                float a[AW];
+                if (DP) {
+#pragma unroll
+                    for (int j = 0; j < AW; ++j) {
+                        a[j] = a_all[0][j];
+#pragma unroll
+                        for (int q = 1; q < WS_R; ++q) a[j] = r == q ? a_all[q][j] : a[j];  // (r is wave-uniform)
+                    }
+                } else {
+                    Planes<AW>::load(l_act[ab(b)][DP ? 0 : r], NE, le, a);
+                }
+                p_step(a, l_msg[b & 1][r]);
+            }
+        };
 #ifdef VS_WS_NOP  // diagnostic: the P wave only keeps the barriers
         for (int b = 0; b < nb; ++b) ws_barrier();
         if (false)
@@ -1733,8 +1755,8 @@ __attribute__((amdgpu_waves_per_eu(NR == 3 ? 3 : E::WS_MIN_WAVES, (NE == 64 && N
         for (int b = 0; b < nb; ++b) {
             const int nr = min(WS_R, k_steps - b * WS_R);
             VS_STAMP(st0);
-            if (nr == WS_R) p_batch(std::true_type{}, b, nr);
-            else p_batch(std::false_type{}, b, nr);
+            if (nr == WS_R) p_batch_full(b);
+            else p_batch_ragged(b, nr);
             VS_STAMP(st2);
             ws_barrier();
 #ifdef VS_WS_STAMP
