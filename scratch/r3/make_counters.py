@@ -20,7 +20,7 @@ KERNELS = {
     "config2": "k_rollout_ws<vs::QQT<0>,false,true,1,4,64,false,3,false>",
     "config3": "k_rollout_ws<vs::QcpT<0>,false,true,1,4,64,false,2,true>",
     "config4": "k_rollout_ws<vs::Qbb,false,true,1,4,64,false,2,false>",
-    "config5": "k_rollout_mixed<true,1>",
+    "config5": "k_rollout_mixed<true,1,false>",
     "large_n": "k_step<vs::QQT<0>,false,true,false,0,false>",
     "pack_traj": "k_pack_traj<vs::QQT<0>,2>",
 }

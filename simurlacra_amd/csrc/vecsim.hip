@@ -241,6 +241,13 @@ struct vs_mixed {
     std::string err;
 };
 
+// some member redraws domain parameters at a reset inside the launch (live randomizer / parameter buffer)
+static bool mixed_redraws(const vs_mixed* m) {
+    for (int q = 0; q < m->n; ++q)
+        if (m->sub[q]->d.dr_n > 0 || m->sub[q]->d.pbuf_n > 0) return true;
+    return false;
+}
+
 static int mixed_upload(vs_mixed* m, const float* const* acts, const int64_t* env_strides, const int64_t* dim_strides,
                         int k_steps) {
     int blocks = 0;
@@ -958,7 +965,7 @@ int vs_mixed_step_random(vs_mixed_handle m, uint64_t seed, int k_steps, int reco
     int rc = mixed_upload(m, nullptr, nullptr, nullptr, k_steps);
     if (rc) return rc;
     launch_rollout_mixed((const Segs*)m->dev, m->total_blocks, m->sub[0]->stream, m->sub[0]->auto_reset,
-                         record ? m->sub[0]->record_mode : 0, k_steps, seed);
+                         record ? m->sub[0]->record_mode : 0, k_steps, seed, mixed_redraws(m));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { m->err = hipGetErrorString(e); return VS_ERR_HIP; }
     return VS_OK;
@@ -971,7 +978,7 @@ int vs_mixed_step(vs_mixed_handle m, const float* const* actions, const int64_t*
     if (hipSetDevice(m->sub[0]->device) != hipSuccess) return VS_ERR_HIP;
     int rc = mixed_upload(m, actions, env_strides, dim_strides, 0);
     if (rc) return rc;
-    launch_step_mixed((const Segs*)m->dev, m->total_blocks, m->sub[0]->stream, m->sub[0]->auto_reset);
+    launch_step_mixed((const Segs*)m->dev, m->total_blocks, m->sub[0]->stream, m->sub[0]->auto_reset, mixed_redraws(m));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { m->err = hipGetErrorString(e); return VS_ERR_HIP; }
     return VS_OK;

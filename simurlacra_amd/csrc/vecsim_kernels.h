@@ -2044,22 +2044,23 @@ struct Segs {
         default: { using E = BobD; __VA_ARGS__; } break;            \
     }
 
-template <bool AR, int REC>
+// DRK: some member handle has a live randomizer or a parameter buffer (see k_rollout_ws): only then do the bodies carry the redraw
+template <bool AR, int REC, bool DRK = false>
 __global__ __launch_bounds__(BLOCK) void k_rollout_mixed(const Segs* __restrict__ segs, int k_steps, uint64_t seed) {
     int b = blockIdx.x, q = 0, first = 0;
     int n = segs->n;
     while (q < n - 1 && b >= segs->s[q].block_end) first = segs->s[q++].block_end;
     const Seg& sg = segs->s[q];
-    MIXED_DISPATCH(sg.type, (rollout_body<E, false, AR, REC>(sg.T, sg.d, k_steps, seed, sg.reset_seed, sg.epoch0, b - first)));
+    MIXED_DISPATCH(sg.type, (rollout_body<E, false, AR, REC, false, DRK>(sg.T, sg.d, k_steps, seed, sg.reset_seed, sg.epoch0, b - first)));
 }
 
-template <bool AR>
+template <bool AR, bool DRK = false>
 __global__ __launch_bounds__(BLOCK) void k_step_mixed(const Segs* __restrict__ segs) {
     int b = blockIdx.x, q = 0, first = 0;
     int n = segs->n;
     while (q < n - 1 && b >= segs->s[q].block_end) first = segs->s[q++].block_end;
     const Seg& sg = segs->s[q];
-    MIXED_DISPATCH(sg.type, (step_body<E, false, AR>(sg.T, sg.d, sg.act, sg.env_stride, sg.dim_stride, sg.reset_seed, b - first)));
+    MIXED_DISPATCH(sg.type, (step_body<E, false, AR, false, 0, DRK>(sg.T, sg.d, sg.act, sg.env_stride, sg.dim_stride, sg.reset_seed, b - first)));
 }
 #endif  // VS_TU_MIXED
 
@@ -2319,8 +2320,8 @@ struct Launch {
 };
 
 // mixed batches: defined in vecsim_mixed.hip
-void launch_rollout_mixed(const Segs* dev_segs, int total_blocks, hipStream_t st, bool ar, int rec, int k_steps, uint64_t seed);
-void launch_step_mixed(const Segs* dev_segs, int total_blocks, hipStream_t st, bool ar);
+void launch_rollout_mixed(const Segs* dev_segs, int total_blocks, hipStream_t st, bool ar, int rec, int k_steps, uint64_t seed, bool drk);
+void launch_step_mixed(const Segs* dev_segs, int total_blocks, hipStream_t st, bool ar, bool drk);
 
 #ifdef VS_TU_FAMILY
 // Which fused kernel for a batch (measured on MI355X, profiles/r02_table_variants.txt; 256 compute units):

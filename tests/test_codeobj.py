@@ -40,7 +40,7 @@ BASELINE_KERNELS = [
     ("config 3: 65 536 cartpole + live DR", "k_rollout_ws<QcpT<0>, false, true, 1, 4, 64, false, 2, true>", 256),  # two waves per SIMD
     ("config 4: 32 768 ball balancer", "k_rollout_ws<Qbb, false, true, 1, 4, 64, false, 2, false>", 256),
     ("ball balancer at 65 536", "k_rollout_ws<Qbb, false, true, 1, 4, 256, false, 2, false>", 256),
-    ("config 5: mixed batch", "k_rollout_mixed<true, 1>(Segs const*, int, unsigned long)", 128),    # four waves per SIMD
+    ("config 5: mixed batch", "k_rollout_mixed<true, 1, false>(Segs const*, int, unsigned long)", 128),    # four waves per SIMD
     ("config 1 / policy in the loop: oscillator step", "k_step<Omo, false, false, false, 0, false>", 128),
     ("large-N step", "k_step<QQT<0>, false, true, false, 0, false>", 128),
 ]
