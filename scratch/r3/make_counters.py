@@ -15,11 +15,11 @@ sys.path.insert(0, ROOT)
 
 # which kernel each leg of the line launches (substring of the demangled name, spaces removed)
 KERNELS = {
-    "headline": "k_rollout_ws<vs::QQT<0>,false,true,1,4,256,false,3,false>",
-    "record2": "k_rollout_ws<vs::QQT<0>,false,true,2,4,256,false,3,false>",
-    "config2": "k_rollout_ws<vs::QQT<0>,false,true,1,4,64,false,3,false>",
-    "config3": "k_rollout_ws<vs::QcpT<0>,false,true,1,4,64,false,2,true>",
-    "config4": "k_rollout_ws<vs::Qbb,false,true,1,4,64,false,2,false>",
+    "headline": "k_rollout_ws<vs::QQT<0>,false,true,1,4,256,false,3,0>",
+    "record2": "k_rollout_ws<vs::QQT<0>,false,true,2,4,256,false,3,0>",
+    "config2": "k_rollout_ws<vs::QQT<0>,false,true,1,4,64,false,3,0>",
+    "config3": "k_rollout_ws<vs::QcpT<0>,false,true,1,4,64,false,2,1>",
+    "config4": "k_rollout_ws<vs::Qbb,false,true,1,4,64,false,2,0>",
     "config5": "k_rollout_mixed<true,1,false>",
     "large_n": "k_step<vs::QQT<0>,false,true,false,0,false>",
     "pack_traj": "k_pack_traj<vs::QQT<0>,2>",

@@ -353,12 +353,15 @@ __device__ __forceinline__ void redraw_lane_params(const Task& T, const Dev& d, 
 // DomainRandWrapperLive redraw (environment_wrappers/domain_randomization.py:141-148) when a randomizer is set.
 // Every draw is a pure function of (seed, env index, episode index epi): independent of launch geometry, of how the
 // steps are chunked into launches and of hipGraph replay.
+// with_dr / with_pbuf are compile-time constants at every call site (inlined): the kernels of a handle without a live randomizer /
+// without a parameter buffer do not carry that block
 template <class E>
 __device__ __forceinline__ void reset_lane_sampled(const Task& T, const Dev& d, bool with_dr, int i, uint64_t seed,
                                                    uint64_t epi, float* c, float* s, float* h,
-                                                   const float* lds_params = nullptr, int lds_pitch = 0, int lds_lane = 0) {
+                                                   const float* lds_params = nullptr, int lds_pitch = 0, int lds_lane = 0,
+                                                   bool with_pbuf = true) {
     if (with_dr && d.dr_n > 0) redraw_lane_params<E>(T, d, &d.drv, i, seed, epi, c, lds_params, lds_pitch, lds_lane);
-    if (with_dr && d.pbuf_n > 0) {
+    if (with_dr && with_pbuf && d.pbuf_n > 0) {
         // DomainRandWrapperBuffer.reset (domain_randomization.py:236-251): next set of the ring, or a random one
         uint32_t k;
         if (d.pbuf_mode == 0) k = (uint32_t)(((uint64_t)d.idx0 + (uint64_t)i + epi) % (uint64_t)d.pbuf_n);
@@ -1388,11 +1391,13 @@ __global__ __launch_bounds__(64 * fnn_waves(NHID)) void k_rollout_fnn(Task T, De
 // launch redraws the lane's domain parameters.  The kernels without it (the headline's, every nominal-parameter batch) carry
 // none of that code -- the redraw (Philox, Box-Muller, the parameter select chains, _calc_constants) was ~1 000 instructions in
 // each of the eight inlined reset blocks of a kernel that never executes it.
-template <class E, bool UNI, bool AR, int REC, int WS_R, int NE, bool DP, int NR = 2, bool DRK = false>
+//   DRK = 0 none, 1 a live randomizer (DomainRandWrapperLive), 2 a parameter buffer (DomainRandWrapperBuffer; or both)
+template <class E, bool UNI, bool AR, int REC, int WS_R, int NE, bool DP, int NR = 2, int DRK = 0>
 __global__ __launch_bounds__(NR * NE)
 __attribute__((amdgpu_waves_per_eu(NR == 3 ? 3 : E::WS_MIN_WAVES, (NE == 64 && NR == 2 && E::WS_ALONE) ? 1 : 0))) void k_rollout_ws(Task T, Dev d, int k_steps, uint64_t seed, uint64_t reset_seed,
                                                         uint64_t epoch0) {
-    static_assert(!DRK || (!UNI && AR), "a randomizer needs per-env constants and resets inside the launch");
+    static_assert(DRK == 0 || (!UNI && AR), "a randomizer needs per-env constants and resets inside the launch");
+    static_assert(DRK >= 0 && DRK <= 2, "none | randomizer | buffer");
     static_assert(E::FINAL != FINAL_STATE_TIME, "needs the post-step state on the reward side");
     static_assert(NE == 64 || NE == 128 || NE == 256, "envs per workgroup");
     static_assert(NR == 2 || (NR == 3 && !DP), "two roles, or three with the generator wave drawing the actions");
@@ -1445,8 +1450,9 @@ __attribute__((amdgpu_waves_per_eu(NR == 3 ? 3 : E::WS_MIN_WAVES, (NE == 64 && N
     //   [P][NE] the parameters of the entry (a redraw overwrites the randomised ones in place; the others are the lane's
     //   parameters at the start of the launch and never change) | [K][NE] the constants calc_consts derives from them
     extern __shared__ float l_dyn[];
-    const bool dr_stock = DRK && STOCK && !UNI && d.dr_n > 0 && d.pbuf_n == 0;     // wave-uniform (false at compile time without DRK)
-    const bool stock_on = STOCK && (!DRK || (d.pbuf_n == 0 && (d.dr_n == 0 || dr_stock)));  // wave-uniform
+    // (wave-uniform; constants at compile time for DRK = 0, and DRK = 1 says there is no parameter buffer)
+    const bool dr_stock = DRK == 1 ? (STOCK && !UNI && d.dr_n > 0) : (DRK == 2 && STOCK && !UNI && d.dr_n > 0 && d.pbuf_n == 0);
+    const bool stock_on = STOCK && (DRK == 0 || (DRK == 1 ? true : (d.pbuf_n == 0 && (d.dr_n == 0 || dr_stock))));
     float* const l_npar = l_dyn;
     float* const l_ncon = l_dyn + E::P * NE;
     const int wave = threadIdx.x >> 6;
@@ -1686,8 +1692,8 @@ __attribute__((amdgpu_waves_per_eu(NR == 3 ? 3 : E::WS_MIN_WAVES, (NE == 64 && N
                             if (!stocked) {
                                 // live domain randomisation redraws the lane's parameters here: allowed for the families
                                 // whose C wave does not read constants (use_ws)
-                                reset_lane_sampled<E>(T, d, DRK, i, reset_seed, (uint64_t)epi, c, s, h,
-                                                      dr_stock ? (const float*)l_npar : (const float*)nullptr, NE, le);
+                                reset_lane_sampled<E>(T, d, DRK != 0, i, reset_seed, (uint64_t)epi, c, s, h,
+                                                      dr_stock ? (const float*)l_npar : (const float*)nullptr, NE, le, DRK == 2);
                                 if (REC) E::observe_p(s, tr);
                             }
                             epi += 1u;
@@ -2395,7 +2401,7 @@ static void launch_ws(vs_env* h, int k, uint64_t seed, uint64_t ep, int rec) {
         // dynamic LDS: the live randomizer's part of the reset stock (see the kernel), only when one is set
         const unsigned dyn = (!U && AR && h->d.dr_n > 0 && h->d.pbuf_n == 0) ? (unsigned)((E::P + E::K) * NE * sizeof(float)) : 0u;
         // the instantiation with the redraw compiled in only for a handle that has a randomizer or a parameter buffer
-        const bool drk = !U && AR && (h->d.dr_n > 0 || h->d.pbuf_n > 0);
+        const int drk = (!U && AR) ? (h->d.pbuf_n > 0 ? 2 : (h->d.dr_n > 0 ? 1 : 0)) : 0;
         // R = 4 steps per exchange (measured on the headline config: R = 1 / 2 / 4 -> 68.7 / 64.8 / 62.0 us per 100 steps)
 #define LWK(REC, DRKV)                                                                                                     \
     {                                                                                                                      \
@@ -2409,8 +2415,8 @@ static void launch_ws(vs_env* h, int k, uint64_t seed, uint64_t ep, int rec) {
     }
 #define LW(REC)                                                                                                            \
     {                                                                                                                      \
-        if constexpr (!U && AR) { if (drk) LWK(REC, true) else LWK(REC, false) }                                            \
-        else LWK(REC, false)                                                                                               \
+        if constexpr (!U && AR) { if (drk == 2) LWK(REC, 2) else if (drk == 1) LWK(REC, 1) else LWK(REC, 0) }               \
+        else LWK(REC, 0)                                                                                                   \
     }
         if (rec == 0) LW(0) else if (rec == 1) LW(1) else LW(2)
 #undef LW
