@@ -25,9 +25,16 @@ pytestmark = pytest.mark.skipif(not os.path.isdir(codeobj.OBJ_DIR) or not os.lis
                                 reason="no in-tree build objects (run __graft_entry__.build())")
 
 
+@pytest.fixture(scope="module", autouse=True)
+def fresh_build():
+    """the code objects read here are those of the sources as they stand: a stale in-tree build is rebuilt first (what
+    __graft_entry__.build() does; ~3 minutes on 8 cores, nothing when the build is current)"""
+    if vbuild.is_stale():
+        vbuild.build()
+
+
 @pytest.fixture(scope="module")
-def rows():
-    assert not vbuild.is_stale(), "libvecsim.so is older than its sources: rebuild before reading the code objects"
+def rows(fresh_build):
     return codeobj.table()
 
 

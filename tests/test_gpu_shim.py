@@ -611,6 +611,28 @@ def test_sample_packed_holds_what_sample_returns(vs, name, policy_kind):
         ParallelRolloutSampler(env, pol, 2, min_steps=100, seed=11).sample_packed()
 
 
+def test_sampler_owned_arrays_and_close(vs):
+    """owned_arrays=True: the rollouts' arrays are pageable copies the caller owns (the default hands out views of one pinned
+    block per call); same values either way; close() releases the device handle and the conversion threads and is idempotent"""
+    from simurlacra_amd.policies import DummyPolicy
+    from simurlacra_amd.sampling import ParallelRolloutSampler
+
+    env = vs.BallOnBeamSim(**dict(KW["bob"], max_steps=40))
+    a = ParallelRolloutSampler(env, DummyPolicy(env.spec), 1, min_rollouts=33, seed=5)
+    b = ParallelRolloutSampler(env, DummyPolicy(env.spec), 1, min_rollouts=33, seed=5, owned_arrays=True)
+    ra, rb = a.sample(), b.sample()
+    assert len(ra) == len(rb) == 33
+    for x, y in zip(ra, rb):
+        for f in ("observations", "actions", "rewards", "states", "actions_applied"):
+            np.testing.assert_array_equal(getattr(x, f), getattr(y, f))
+    base_a = ra[0].observations.base if ra[0].observations.base is not None else ra[0].observations
+    assert any(r.observations.base is not None and np.shares_memory(r.observations, ra[0].observations.base) for r in ra[1:])  # views of ONE block
+    assert not np.shares_memory(rb[0].observations, rb[1].observations) or rb[0].observations.base is rb[1].observations.base
+    a.close(), b.close()
+    a.close()  # idempotent
+    assert len(a.sample()) == 33  # a closed sampler builds its handle again
+
+
 @pytest.mark.parametrize("name", ["omo", "bob", "qq-su", "qcp-su", "qbb", "pend"])
 @pytest.mark.parametrize("mode", [1, 2])
 def test_pack_traj_kernel_equals_the_index_gather(vs, name, mode):
