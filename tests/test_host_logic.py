@@ -472,20 +472,26 @@ def test_fnn_policy_mirror_and_kernel_spec():
 
 
 def test_packed_rollouts_indexing():
-    """PackedRollouts: the slices of rollout j in the per-step tensors and in the tensors with one entry more than steps, the
-    rollout index of every packed step, per-rollout returns (CPU tensors: the container does not care where they live)"""
+    """PackedRollouts: ONE matrix rows[total + n, F], rollout j in rows offsets[j] + j .. offsets[j + 1] + j (its steps, then the
+    entry behind them), every field a view of it indexed by the same rows: the slices of rollout j, the rollout of every row and of
+    every step, the rows of all steps, per-rollout returns (CPU tensors: the container does not care where they live)"""
     torch = pytest.importorskip("torch")
     from simurlacra_amd.sampling import PackedRollouts
 
     lengths = torch.tensor([3, 1, 4])
     starts = torch.cumsum(lengths, 0) - lengths
-    total, n = int(lengths.sum()), 3
-    p = PackedRollouts(observations=torch.arange((total + n) * 2, dtype=torch.float32).reshape(total + n, 2),
-                       actions=torch.zeros(total, 1), rewards=torch.arange(total, dtype=torch.float32), states=None,
+    total, n, F = int(lengths.sum()), 3, 4  # record: [obs (2) | act | rew]
+    rows = torch.zeros(total + n, F)
+    rows[:, :2] = torch.arange((total + n) * 2, dtype=torch.float32).reshape(total + n, 2)
+    p = PackedRollouts(rows=rows, observations=rows[:, :2], actions=rows[:, 2:3], rewards=rows[:, 3], states=None,
                        actions_applied=None, th_ddot=None, lengths=lengths, offsets=torch.cat([starts, starts[-1:] + lengths[-1:]]),
-                       done_last=torch.tensor([True, False, True]), init_states=torch.zeros(n, 2), first_index=0)
+                       total=total, done_last=torch.tensor([True, False, True]), init_states=torch.zeros(n, 2), first_index=0)
     assert len(p) == 3 and p.total_steps == 8
-    assert [p.step_slice(j) for j in range(3)] == [slice(0, 3), slice(3, 4), slice(4, 8)]
-    assert [p.obs_slice(j) for j in range(3)] == [slice(0, 4), slice(4, 6), slice(6, 11)]  # len + 1 entries each, back to back
+    assert [p.step_slice(j) for j in range(3)] == [slice(0, 3), slice(4, 5), slice(6, 10)]   # the steps of rollout j ...
+    assert [p.obs_slice(j) for j in range(3)] == [slice(0, 4), slice(4, 6), slice(6, 11)]    # ... and the entry behind them
     assert p.rollout_index().tolist() == [0, 0, 0, 1, 2, 2, 2, 2]
+    assert p.row_rollout_index().tolist() == [0, 0, 0, 0, 1, 1, 2, 2, 2, 2, 2]
+    assert p.step_rows().tolist() == [0, 1, 2, 4, 6, 7, 8, 9]
+    rows[p.step_rows(), 3] = torch.arange(total, dtype=torch.float32)   # rewards 0 .. 7 on the step rows, 0 on the final entries
     assert p.undiscounted_returns().tolist() == [3.0, 3.0, 22.0]
+    assert p.actions[p.step_rows()].shape == (total, 1)  # the dense, reference-style concatenation
