@@ -21,7 +21,7 @@ KERNELS = {
     "config3": "k_rollout_ws<vs::QcpT<0>,false,true,1,4,64,false,2,1>",
     "config4": "k_rollout_ws<vs::Qbb,false,true,1,4,64,false,2,0>",
     "config5": "k_rollout_mixed<true,1,false>",
-    "large_n": "k_step<vs::QQT<0>,false,true,false,0,false>",
+    "large_n": "k_step<vs::QQT<0>,false,true,false,0,false,true>",
     "pack_traj": "k_pack_traj<vs::QQT<0>,2>",
 }
 

@@ -66,6 +66,14 @@ def kernels_of(obj_path):
     return rows
 
 
+def disassemble(obj_path, mangled_name):
+    """the ISA of one kernel of a translation unit (llvm-objdump of its gfx950 code object)"""
+    with tempfile.TemporaryDirectory() as tmp:
+        co = device_code_object(obj_path, os.path.join(tmp, "dev.co"))
+        return subprocess.run([_tool("llvm-objdump"), "-d", "--no-show-raw-insn", f"--disassemble-symbols={mangled_name}", co],
+                              capture_output=True, text=True, check=True).stdout
+
+
 def table(obj_dir=OBJ_DIR):
     rows = []
     for fn in sorted(os.listdir(obj_dir)):

@@ -301,11 +301,25 @@ __device__ __forceinline__ StepOutT<R> step_one(const Task& T, const float* c, R
     return o;
 }
 
-template <class E, bool UNI>
+// Non-temporal access for the single-step kernel at large batch sizes (NT): one step of 16.7 M envs touches 2 GB once per
+// launch -- nothing of it is in a cache when the next launch comes, and keeping it out of the caches' way is worth 27 % there
+// (k_step at 16.7 M QQube envs, same box: 0.57 -> 0.73 of HBM); up to ~2 M envs the working set lives in the 256 MB Infinity
+// Cache from one launch to the next and the default policy is the right one (STEP_NT_MIN_ENVS).
+template <bool NT, class V>
+__device__ __forceinline__ V ld_nt(const V* p) {
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+    else return *p;
+}
+template <bool NT, class V>
+__device__ __forceinline__ void st_nt(V v, V* p) {
+    if constexpr (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
+template <class E, bool UNI, bool NT = false>
 __device__ __forceinline__ void load_consts(const Dev& d, int i, float* c, int first, int last) {
 #pragma unroll
     for (int k = 0; k < E::K; ++k)
-        if (k >= first && k < last) c[k] = UNI ? d.consts_uni[k] : d.consts[(size_t)k * d.ld + i];
+        if (k >= first && k < last) c[k] = UNI ? d.consts_uni[k] : ld_nt<NT>(&d.consts[(size_t)k * d.ld + i]);
 }
 
 // DomainRandomizer.randomize for one lane (domain_parameter.py:104-132): draw -> clamp; writes the raw params
@@ -567,22 +581,22 @@ __device__ __forceinline__ void applied_action(const Task& T, const float* c, co
 // action, the reward, and in mode 2 the state and hidden state before the step and env.limit_act(act) -- into row `row` of
 // the VS_TRAJ_* buffers, or, for row < 0, into the row the handle's device-side counter names (Dev::rec_row: a captured
 // hipGraph replays with the counter advanced by k_bump_row between the steps).  Rows beyond the capacity are not written.
-template <class E, bool UNI, bool AR, bool PIPE = false, int REC = 0, bool DRK = !UNI>
+template <class E, bool UNI, bool AR, bool PIPE = false, int REC = 0, bool DRK = !UNI, bool NT = false>
 __device__ __forceinline__ void step_body(const Task& T, const Dev& d, const float* __restrict__ act, long env_stride,
                                           long dim_stride, uint64_t seed, int block, int row = 0) {
     int i = block * BLOCK + threadIdx.x;
     if (i >= d.ld) return;
     const size_t ld = d.ld;
     float c[E::K], s[E::S], h[E::H > 0 ? E::H : 1], a[E::A];
-    load_consts<E, UNI>(d, i, c, 0, E::KS);
+    load_consts<E, UNI, NT>(d, i, c, 0, E::KS);
 #pragma unroll
-    for (int j = 0; j < E::S; ++j) s[j] = d.state[j * ld + i];
+    for (int j = 0; j < E::S; ++j) s[j] = ld_nt<NT>(&d.state[j * ld + i]);
 #pragma unroll
-    for (int j = 0; j < E::H; ++j) h[j] = d.hidden[j * ld + i];
+    for (int j = 0; j < E::H; ++j) h[j] = ld_nt<NT>(&d.hidden[j * ld + i]);
     bool valid = i < d.n;
 #pragma unroll
-    for (int j = 0; j < E::A; ++j) a[j] = valid ? act[(size_t)i * env_stride + (size_t)j * dim_stride] : 0.f;
-    int step = d.step[i];
+    for (int j = 0; j < E::A; ++j) a[j] = valid ? ld_nt<NT>(&act[(size_t)i * env_stride + (size_t)j * dim_stride]) : 0.f;
+    int step = ld_nt<NT>(&d.step[i]);
     bool yielded = E::FINAL != FINAL_NONE ? d.yielded[i] != 0 : false;
     const bool noisy = PIPE && (d.pipe.act_noise | d.pipe.obs_noise);  // wave-uniform
     uint32_t epi = noisy ? d.ep_idx[i] : 0u;
@@ -625,7 +639,7 @@ __device__ __forceinline__ void step_body(const Task& T, const Dev& d, const flo
     const bool lean = (T.flags & VS_FLAG_LEAN_STEP) != 0;
     float ret = 0.f;
     if (!lean) ret = d.ret[i] + o.rew;
-    d.rew[i] = o.rew;
+    st_nt<NT>(o.rew, &d.rew[i]);
     d.done[i] = o.done;
     if (!lean) d.failed[i] = o.failed;
     if (o.err && valid) d.err[i] = 1;  // sticky, write-only
@@ -652,20 +666,20 @@ __device__ __forceinline__ void step_body(const Task& T, const Dev& d, const flo
         pipe_obs<E>(d, i, epi, step, ob, ob);
     }
 #pragma unroll
-    for (int j = 0; j < E::S; ++j) d.state[j * ld + i] = s[j];
+    for (int j = 0; j < E::S; ++j) st_nt<NT>(s[j], &d.state[j * ld + i]);
 #pragma unroll
-    for (int j = 0; j < E::H; ++j) d.hidden[j * ld + i] = h[j];
+    for (int j = 0; j < E::H; ++j) st_nt<NT>(h[j], &d.hidden[j * ld + i]);
 #pragma unroll
-    for (int j = 0; j < E::O; ++j) d.obs[j * ld + i] = ob[j];
-    d.step[i] = step;
+    for (int j = 0; j < E::O; ++j) st_nt<NT>(ob[j], &d.obs[j * ld + i]);
+    st_nt<NT>(step, &d.step[i]);
     if (!lean) d.ret[i] = ret;
     if (E::FINAL != FINAL_NONE) d.yielded[i] = yielded;
 }
 
-template <class E, bool UNI, bool AR, bool PIPE, int REC, bool DRK = false>
+template <class E, bool UNI, bool AR, bool PIPE, int REC, bool DRK = false, bool NT = false>
 __global__ __launch_bounds__(BLOCK) void k_step(Task T, Dev d, const float* __restrict__ act, long env_stride,
                                                 long dim_stride, uint64_t seed, int row) {
-    step_body<E, UNI, AR, PIPE, REC, DRK>(T, d, act, env_stride, dim_stride, seed, (int)blockIdx.x, row);
+    step_body<E, UNI, AR, PIPE, REC, DRK, NT>(T, d, act, env_stride, dim_stride, seed, (int)blockIdx.x, row);
 }
 
 // ---------------------------------------------------------------------------------------------------- Jacobian kernel
@@ -2122,6 +2136,7 @@ __global__ __launch_bounds__(BLOCK) void k_pack_traj(Dev d, int n, const long lo
     // the records of tile k + 1 are loaded into registers BEFORE tile k's store side runs, and the two barriers of a tile wait
     // for LDS traffic only (ws_barrier: lgkmcnt, not vmcnt): the global stores of a tile stay in flight behind it
     constexpr int RPW = TT / 4;  // steps of a tile per wave on the load side
+    // (non-temporal loads of the planes and stores of the rows were measured: 3.96 -> 3.28 TB/s full-length, 2.79 -> 2.46 ragged)
     float v[RPW][F];
     auto fetch = [&](int tb) __attribute__((always_inline)) {
 #pragma unroll
@@ -2374,11 +2389,26 @@ int Launch<E>::variant(vs_env* h) {
     return RV_PLAIN;
 }
 
+// from 4 M envs on (0.5 GB per step: twice the Infinity Cache); measured NT against default, QQube, lean: 1 M + 10 %, 2 M - 7 %,
+// 4 M + 7 %, 16.7 M + 24 %
+constexpr int64_t STEP_NT_MIN_ENVS = 4 << 20;
 template <class E, int REC>
 static void launch_step_rec(vs_env* h, const float* act, long es, long ds, int row) {
     dim3 g = grid_for(h->d.ld), b(BLOCK);
     bool uni = h->uniform && h->dr.n == 0 && h->d.pbuf_n == 0;
     const bool drk = h->d.dr_n > 0 || h->d.pbuf_n > 0;  // a reset inside the launch redraws domain parameters
+    if constexpr (REC == 0) {
+        // large batches: the non-temporal instantiation (see ld_nt); VS_STEP_NT=0|1 overrides (experiments)
+        static const char* nt_env = getenv("VS_STEP_NT");
+        const bool nt = nt_env ? nt_env[0] == '1' : (int64_t)h->d.ld >= STEP_NT_MIN_ENVS;
+        if (nt && !(h->d.pipe.act_on || h->d.pipe.obs_on) && !drk) {
+#define LN(U, AR) hipLaunchKernelGGL((k_step<E, U, AR, false, 0, false, true>), g, b, 0, h->stream, h->task, h->d, act, es, ds, h->ar_seed, row)
+            if (h->auto_reset) { if (uni) LN(true, true); else LN(false, true); }
+            else { if (uni) LN(true, false); else LN(false, false); }
+#undef LN
+            return;
+        }
+    }
 #define LS(U, AR, PI, DK) hipLaunchKernelGGL((k_step<E, U, AR, PI, REC, DK>), g, b, 0, h->stream, h->task, h->d, act, es, ds, h->ar_seed, row)
     if (h->d.pipe.act_on || h->d.pipe.obs_on) {  // the wrapper pipeline: per-env-constant variant only
         if (h->auto_reset) { if (drk) LS(false, true, true, true); else LS(false, true, true, false); } else LS(false, false, true, false);

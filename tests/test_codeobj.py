@@ -5,8 +5,9 @@ kernel 35 spills / 144 B per lane, the ball balancer's 177 / 712 B, the headline
 loop-invariant address arithmetic of the rare reset / redraw blocks hoisted out of the step loop (`cold_lane` in
 csrc/vecsim_kernels.h); this file keeps it from coming back:
 
-  * the kernel `vs_step_random` launches for every BASELINE configuration: vgpr_spill_count == 0 and
-    private_segment_fixed_size == 0, and a VGPR budget that keeps the occupancy the launcher counts on;
+  * the kernel `vs_step_random` launches for every BASELINE configuration: vgpr_spill_count == 0, private_segment_fixed_size == 0
+    (or a dead frame object of a few bytes that no instruction of the kernel refers to, see below), and a VGPR budget that
+    keeps the occupancy the launcher counts on;
   * every kernel of the library: not one scratch instruction in its ISA (a few kernels keep a dead 36-byte frame object
     from SGPR spill slots that were lowered to VGPR lanes -- the disassembly is the check that nothing touches it), and no
     VGPR spill except the in-kernel policy's deepest shapes, which spill into AGPRs, not memory.
@@ -41,6 +42,7 @@ def rows(fresh_build):
 # (BASELINE config, demangled kernel name, VGPR ceiling): the automatic choice of Launch<E>::variant for that batch on 256 CUs,
 # per-env constants (what bench.py and the samplers run), auto-reset, record mode 1; the last template argument (DRK) says
 # whether the redraw of a live randomizer is compiled in: config 3's kernel only
+SCRATCH_INSN = re.compile(r"\bscratch_(load|store)|\bbuffer_(load|store)\w* .*\boffen\b")
 BASELINE_KERNELS = [
     ("headline: 65 536 QQube", "k_rollout_ws<QQT<0>, false, true, 1, 4, 256, false, 3, 0>", 168),   # three waves per SIMD
     ("config 2: 4 096 QQube", "k_rollout_ws<QQT<0>, false, true, 1, 4, 64, false, 3, 0>", 168),
@@ -48,8 +50,8 @@ BASELINE_KERNELS = [
     ("config 4: 32 768 ball balancer", "k_rollout_ws<Qbb, false, true, 1, 4, 64, false, 2, 0>", 256),
     ("ball balancer at 65 536", "k_rollout_ws<Qbb, false, true, 1, 4, 256, false, 2, 0>", 256),
     ("config 5: mixed batch", "k_rollout_mixed<true, 1, false>(Segs const*, int, unsigned long)", 128),    # four waves per SIMD
-    ("config 1 / policy in the loop: oscillator step", "k_step<Omo, false, false, false, 0, false>", 128),
-    ("large-N step", "k_step<QQT<0>, false, true, false, 0, false>", 128),
+    ("config 1 / policy in the loop: oscillator step", "k_step<Omo, false, false, false, 0, false, false>", 128),
+    ("large-N step", "k_step<QQT<0>, false, true, false, 0, false, true>", 128),
 ]
 
 
@@ -59,9 +61,14 @@ def test_baseline_config_kernels_have_no_scratch(rows, what, name, vgpr_cap):
     assert len(hit) == 1, f"{name}: {len(hit)} kernels of that name in the build"
     r = hit[0]
     assert r["vgpr_spill_count"] == 0, r
-    assert r["private_segment_fixed_size"] == 0, r
     assert not r.get("uses_dynamic_stack"), r
     assert r["vgpr_count"] + r["agpr_count"] <= vgpr_cap, r
+    if r["private_segment_fixed_size"] != 0:
+        # LLVM sometimes leaves a dead frame object behind when it lowers SGPR spills to VGPR lanes (8 .. 68 bytes, which
+        # instantiations get one changes with unrelated edits): accepted only if NOT ONE instruction of this kernel touches scratch
+        assert r["sgpr_spill_count"] > 0 and r["private_segment_fixed_size"] <= 68, r
+        isa = codeobj.disassemble(os.path.join(codeobj.OBJ_DIR, r["unit"]), r["name"])
+        assert isa.count("\n") > 100 and not SCRATCH_INSN.search(isa), (name, r["private_segment_fixed_size"])
 
 
 def test_every_fused_kernel_family_is_spill_free(rows):
@@ -92,7 +99,7 @@ def test_wave_specialised_kernels_keep_their_occupancy(rows):
 def test_no_kernel_executes_a_scratch_instruction():
     """The ISA of every translation unit: no scratch_load / scratch_store / buffer access off the scratch descriptor."""
     objdump = codeobj._tool("llvm-objdump")
-    pat = re.compile(r"\bscratch_(load|store)|\bbuffer_(load|store)\w* .*\boffen\b")
+    pat = SCRATCH_INSN
     for fn in sorted(os.listdir(codeobj.OBJ_DIR)):
         if not fn.endswith(".o"):
             continue
