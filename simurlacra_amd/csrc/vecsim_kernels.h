@@ -2109,33 +2109,30 @@ __global__ __launch_bounds__(BLOCK) void k_pack_traj(Dev d, int n, const long lo
 #else
     constexpr int TT = F > 16 ? 8 : 16;   // steps per tile: 64 x TT x F floats of LDS (QQube, full records: 53 KB)
 #endif
-    constexpr int RUN = TT * F;           // floats of a lane's run in the destination
-    constexpr int RS = RUN + 1;           // odd row stride: the load side writes a column across 64 rows without bank conflicts
+    constexpr int RUN = TT * F;           // floats of a lane's TT steps in the destination
+    constexpr int CA = 32;                // floats of a 128-byte line: the carry area in front of a lane's LDS row (below)
+    constexpr int RS = (CA + RUN) | 1;    // odd row stride: the load side writes a column across 64 rows without bank conflicts
     static_assert(BLOCK == 256 && PK_SEG % TT == 0 && TT % 4 == 0, "four waves per workgroup");
-    __shared__ float tile[PK_LANES * RS];
-    __shared__ long long l_row[PK_LANES];  // first destination row of the workgroup's lanes: start[lane] + lane
-    __shared__ int l_len[PK_LANES];        // their rollout lengths (0 for lanes beyond n)
-    __shared__ int l_max;
+    __shared__ float tile[PK_LANES * RS];   // [lane][carry area | TT x F floats]: 61.7 KB for the QQube's full records
     const int lane0 = blockIdx.x * PK_LANES;
-    const int tid = threadIdx.x, wave = tid >> 6, l = tid & 63;
+    const int tid = threadIdx.x, l = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const size_t ld = d.ld;
-    if (tid == 0) l_max = 0;
-    __syncthreads();
-    if (tid < PK_LANES) {
-        const int i = lane0 + tid;
-        const int L = i < n ? (int)len[i] : 0;
-        l_len[tid] = L;
-        l_row[tid] = i < n ? start[i] + (long long)i : 0;
-        atomicMax(&l_max, L);
-    }
-    __syncthreads();
+    // every wave holds the 64 lanes' lengths and first destination rows (start[lane] + lane) in registers, one lane each; the
+    // store side fetches them with v_readlane (the lane it serves is wave-uniform)
+    const int i = lane0 + l;
+    const int myL = i < n ? (int)len[i] : 0;
+    const long long myRow = i < n ? start[i] + (long long)i : 0;
+    const int rowLo = (int)(unsigned)myRow, rowHi = (int)(myRow >> 32);
+    int l_max = myL;
+#pragma unroll
+    for (int o = 32; o; o >>= 1) l_max = max(l_max, __shfl_xor(l_max, o));
     const int seg0 = blockIdx.y * PK_SEG;
     const int seg1 = min(seg0 + PK_SEG, l_max);
-    const int i = lane0 + l;
-    const int myL = l_len[l];
     // the records of tile k + 1 are loaded into registers BEFORE tile k's store side runs, and the two barriers of a tile wait
     // for LDS traffic only (ws_barrier: lgkmcnt, not vmcnt): the global stores of a tile stay in flight behind it
     constexpr int RPW = TT / 4;  // steps of a tile per wave on the load side
+    constexpr int LPW = PK_LANES / 4;  // lanes of a tile per wave on the store side
     // (non-temporal loads of the planes and stores of the rows were measured: 3.96 -> 3.28 TB/s full-length, 2.79 -> 2.46 ragged)
     float v[RPW][F];
     auto fetch = [&](int tb) __attribute__((always_inline)) {
@@ -2145,6 +2142,7 @@ __global__ __launch_bounds__(BLOCK) void k_pack_traj(Dev d, int n, const long lo
             if (t < myL) Planes<F>::load(d.traj_rec + (size_t)t * F * ld, ld, i, v[r]);
         }
     };
+    typedef float f4 __attribute__((ext_vector_type(4)));
     if (seg0 < seg1) fetch(seg0);
     for (int tb = seg0; tb < seg1; tb += TT) {
         // ---- load side: wave w took steps tb + w * (TT / 4) .. of the tile, a lane its own record
@@ -2153,22 +2151,50 @@ __global__ __launch_bounds__(BLOCK) void k_pack_traj(Dev d, int n, const long lo
             const int ts = wave * RPW + r;
             if (tb + ts < myL) {
 #pragma unroll
-                for (int f = 0; f < F; ++f) tile[l * RS + ts * F + f] = v[r][f];
+                for (int f = 0; f < F; ++f) tile[l * RS + CA + ts * F + f] = v[r][f];
             }
         }
         ws_barrier();
         if (tb + TT < seg1) fetch(tb + TT);  // (in flight while this tile is stored)
-        // ---- store side: lane ln's run of min(TT, len - tb) x F floats, thread by thread
-        for (int e = tid; e < PK_LANES * RUN; e += BLOCK) {
-            const int ln = e / RUN, r = e - ln * RUN;
-            const int nv = min(TT, l_len[ln] - tb) * F;
-            if (r < nv) rows[(size_t)(l_row[ln] + tb) * F + r] = tile[ln * RS + r];
+        // ---- store side: wave w writes for lanes 16 w .. 16 w + 15, one lane at a time (which lane, its length and its row are
+        // wave-uniform), 16 bytes per thread, WHOLE 128-BYTE LINES of the destination only: a lane's steps are one contiguous
+        // stream there, but a tile's piece of it (TT x F floats) neither starts nor ends on a line (rows are F x 4 bytes, F odd
+        // for most families), and a line written in two halves a tile apart costs the memory side two partial writes (measured:
+        // rows padded to 64 bytes -- 23 % more bytes written -- took 3 % LESS time).  So the piece behind the last line boundary
+        // (< 32 floats) is carried in LDS in front of the lane's row and goes out with the next tile; a lane's last tile in this
+        // workgroup's segment flushes everything.
+#pragma unroll 2
+        for (int j = 0; j < LPW; ++j) {
+            const int ln = wave * LPW + j;
+            const int Lj = __builtin_amdgcn_readlane(myL, ln);
+            const int nv = min(TT, Lj - tb) * F;
+            if (nv <= 0) continue;
+            const long long row = ((long long)__builtin_amdgcn_readlane(rowHi, ln) << 32) | (unsigned)__builtin_amdgcn_readlane(rowLo, ln);
+            float* base = rows + (size_t)(row + tb) * F;        // where the tile's first float goes
+            const uintptr_t bb = (uintptr_t)base;
+            const bool flush = tb + TT >= Lj || tb + TT >= seg0 + PK_SEG;
+            const int relP = tb > seg0 ? -(int)((bb & 127) >> 2) : 0;               // first float not written yet (<= 0: carried)
+            const int relA = (int)((long long)(((bb + 4 * (long long)relP) & ~(uintptr_t)15) - bb) >> 2);   // ... down to 16 bytes
+            const int relQ = flush ? nv : (int)((((bb + 4 * (uintptr_t)nv) & ~(uintptr_t)127) - bb) >> 2);  // end of what goes out now
+            const float* src = tile + ln * RS + CA;             // src[r] = float r of the tile's piece, src[-c ..] the carry
+            for (int q = relA + 4 * l; q < relQ; q += 256) {
+                if (q >= relP && q + 4 <= relQ) {
+                    f4 x = {src[q], src[q + 1], src[q + 2], src[q + 3]};
+                    *(f4*)(base + q) = x;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (q + k >= relP && q + k < relQ) base[q + k] = src[q + k];
+                }
+            }
+            const int c = nv - relQ;   // carried into the next tile (0 after a flush)
+            if (l < c) tile[ln * RS + CA - c + l] = src[relQ + l];
         }
         ws_barrier();  // the tile has been read (LDS only: the global stores stay in flight)
     }
     // ---- the entry behind a rollout's last step: the frozen lane's final observation / state (by the segment that holds it)
     if (wave == 0 && myL > 0 && myL - 1 >= seg0 && myL - 1 < seg0 + PK_SEG) {
-        float* fin = rows + (size_t)(l_row[l] + myL) * F;
+        float* fin = rows + (size_t)(myRow + myL) * F;
 #pragma unroll
         for (int f = 0; f < F; ++f) fin[f] = 0.f;
 #pragma unroll

@@ -695,6 +695,54 @@ def test_pack_traj_kernel_equals_the_index_gather(vs, name, mode):
     e.close()
 
 
+@pytest.mark.parametrize("name,mode", [("qq-su", 2), ("qq-su", 1), ("qbb", 2), ("omo", 1)])
+@pytest.mark.parametrize("misalign", [0, 1, 7])
+def test_pack_traj_whole_lines_across_tiles_and_segments(vs, name, mode, misalign):
+    """vs_pack_traj writes whole 128-byte lines and carries the piece behind a tile's last line boundary into the next tile:
+    rollouts of 1 .. 700 steps (through the kernel's 256-step segments: a segment's last tile flushes, the next segment starts on
+    whatever byte it starts), lengths at and around the tile and segment sizes, n not a multiple of 64, and the destination
+    matrix at 4-byte alignment only (the C-ABI takes any float*): every row against the index gather, nothing written outside."""
+    import ctypes as C
+
+    import torch
+
+    n, T = 130, 700
+    e = vs.VecSimEnv(name, n, **dict(KW[name], max_steps=10 ** 6))
+    e.set_auto_reset(False)
+    e.reset(seed=2)
+    e.set_record_mode(mode)
+    e.set_traj_capacity(T)
+    e.step_random(T, seed=4, record=True)
+    e.sync()
+    tt = e.traj_tensors(T, n)
+    ar = torch.arange(n, device="cuda")
+    length = 1 + (ar * 131) % T
+    for k, v in enumerate((1, 2, 15, 16, 17, 255, 256, 257, 272, 511, 512, 513, 700, 699, 32, 48)):
+        length[k * 8] = v
+    start = torch.cumsum(length, 0) - length
+    total = int(length.sum())
+    F = e.traj_layout()[0]
+    guard = 64
+    sentinel = -1.2345e30
+    buf = torch.full((guard + misalign + (total + n) * F + guard,), sentinel, device="cuda")
+    rows = buf[guard + misalign:guard + misalign + (total + n) * F]
+    assert rows.data_ptr() % 16 == (4 * misalign) % 16
+    e._check(e._lib.vs_pack_traj(e._h, n, T, C.c_void_p(length.data_ptr()), C.c_void_p(start.data_ptr()), C.c_void_p(rows.data_ptr())),
+             "vs_pack_traj")
+    torch.cuda.synchronize()
+    assert bool((buf[:guard + misalign] == sentinel).all()) and bool((buf[guard + misalign + (total + n) * F:] == sentinel).all())
+    rows = rows.view(total + n, F)
+    lane = torch.repeat_interleave(ar, length)
+    t_idx = torch.arange(total, device="cuda") - start[lane]
+    step_row = torch.arange(total, device="cuda") + lane
+    assert torch.equal(rows[step_row].view(torch.int32), tt["rec"][t_idx, lane].contiguous().view(torch.int32))  # (bit patterns)
+    fin = rows[start + length + ar]
+    O, A = e.dims["O"], e.dims["A"]
+    assert torch.equal(fin[:, :O].contiguous().view(torch.int32), e.tensor(vs._lib.VS_OBS)[:, :n].t().contiguous().view(torch.int32))
+    assert float(fin[:, O:O + A + 1].abs().max()) == 0.0  # (action and reward of the entry behind the last step)
+    e.close()
+
+
 @pytest.mark.parametrize("name", ["qq-su", "bob"])
 def test_graph_policy_path_equals_the_eager_one(vs, name):
     """graph_policy=True: a torch policy stepped through a replayed hipGraph of 32 (observation, policy, recording step)
