@@ -257,6 +257,8 @@ struct EnvDefaults {
     // oscillator / pendulum -10 .. -20 %; ball-on-beam, cartpole and ball balancer, whose physics wave is the long one by
     // itself, gain nothing and keep two waves)
     static constexpr bool WS_G3 = false;
+    // ... and the workgroup shape of the three-role kernel at one workgroup's worth of envs per compute unit (65 536 envs)
+    static constexpr int WS_G3_FULL = 256;
     // ... and how many waves per SIMD its two-role kernel must leave room for (the register budget the compiler gets: 512 / n)
     static constexpr int WS_MIN_WAVES = 1;
     // ... and whether the two waves of its 64-env workgroups want a SIMD each (at most one wave per SIMD: see k_rollout_ws)
@@ -533,6 +535,12 @@ struct QcpT : EnvDefaults<1> {
     // 400 recorded steps in 256-env workgroups -- the inherited default; round 2 had measured the two the other way round)
     static constexpr bool WS_MID = false;
     static constexpr int WS_PREP_C = 1;  // a chain of four dependent _dynamics evaluations: every instruction off it counts
+    // three waves per 64 envs since round 3 (the swing-up task; the stabilisation task's final reward keeps it on k_rollout): with
+    // 125 instead of 256 registers the shape fits, and the generator wave takes the draws and the reset stock -- under a live
+    // randomizer the stock's refill passes (~9 000 cycles each) -- off the reward wave the physics wave waits for:
+    // 65 536 envs + 7 randomised parameters 1.033e11 -> 1.046e11, without a randomizer 1.109e11 -> 1.125e11 (64-env workgroups)
+    static constexpr bool WS_G3 = V == 0;
+    static constexpr int WS_G3_FULL = 64;
     static constexpr int WS_MIN_WAVES = 2;  // 65 536 envs in 64-env workgroups are two waves per SIMD: at most 256 VGPRs
     static constexpr bool SYMMETRIC_BOX = V == 0;
     static constexpr int FINAL = V == 1 ? FINAL_STATE_TIME : FINAL_NONE;

@@ -1452,7 +1452,11 @@ __attribute__((amdgpu_waves_per_eu(NR == 3 ? 3 : E::WS_MIN_WAVES, (NE == 64 && N
     // itself as before -- the values are the same either way (same Philox counters).
     constexpr bool STOCK = AR;
     constexpr int SKW = E::I + (REC ? E::TRIG : 0);
+#ifdef VS_WS_REFILL  // (experiments)
+    constexpr int WS_REFILL = VS_WS_REFILL;
+#else
     constexpr int WS_REFILL = 8;
+#endif
     __shared__ float l_stock[STOCK ? SKW * NE : 1];
     __shared__ uint32_t l_stag[STOCK ? NE : 1];
     __shared__ uint32_t l_epi[(STOCK && G3) ? NE : 1];  // G3: the P wave publishes a lane's episode counter at its resets
@@ -1539,7 +1543,18 @@ __attribute__((amdgpu_waves_per_eu(NR == 3 ? 3 : E::WS_MIN_WAVES, (NE == 64 && N
         if (!STOCK) return;
         if (G3) c_epi = __hip_atomic_load(&l_epi[le], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         const bool need = stock_on && valid && c_tag != c_epi;
-        if (__builtin_amdgcn_ballot_w64(need) == 0ull) return;
+        // Under a live randomizer a pass costs the wave that runs it ~9 000 cycles whether one lane needs an entry or all 64 do (every
+        // lane walks through the draws, the stores are masked), and the physics wave ends up waiting for that wave: a pass for
+        // one or two lanes costs more than the stock misses it prevents.  So a pass waits until WS_REFILL_MIN lanes need one
+        // (the first fill of a launch always runs: every lane does).  Measured, cartpole + 7 parameters, 65 536 envs, 400 steps
+        // per launch: a pass every 8 batches for any lane 9.58e10; every 32 batches 1.0e11; first fill only 1.032e11; every 8
+        // batches once 8 lanes wait 1.033e11 (and 4: 1.02e11, 16: 1.033e11) -- which, unlike "never", still refills in long launches.
+#ifdef VS_WS_REFILL_MIN  // (experiments)
+        constexpr int REFILL_MIN = DRK == 1 ? VS_WS_REFILL_MIN : 1;
+#else
+        constexpr int REFILL_MIN = DRK == 1 ? 8 : 1;
+#endif
+        if (__builtin_popcountll(__builtin_amdgcn_ballot_w64(need)) < REFILL_MIN) return;
         const int i = VS_COLD(i_), le = VS_COLD(le_);  // shadow the kernel's: see cold_lane
         if (dr_stock) {
             // DomainRandWrapperLive.reset of episode c_epi: DomainRandomizer.randomize's draws in their order
@@ -2406,7 +2421,7 @@ int Launch<E>::variant(vs_env* h) {
         // redraw then stalls one trio of waves instead of four), 256-env workgroups (one per CU, a wave of each role on every
         // SIMD) up to 256; beyond that the two-role shape has its third wave per SIMD from the envs themselves
         if (ld <= 128 * cu) return RV_WS64G;
-        if (ld <= 256 * cu) return live ? RV_WS64G : RV_WS256G;
+        if (ld <= 256 * cu) return (live || E::WS_G3_FULL == 64) ? RV_WS64G : RV_WS256G;
     }
     if (ld <= E::WS_SMALL * cu) return RV_WS64;
     if (!E::WS_PAYS) return RV_PLAIN;

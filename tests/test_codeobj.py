@@ -46,8 +46,8 @@ SCRATCH_INSN = re.compile(r"\bscratch_(load|store)|\bbuffer_(load|store)\w* .*\b
 BASELINE_KERNELS = [
     ("headline: 65 536 QQube", "k_rollout_ws<QQT<0>, false, true, 1, 4, 256, false, 3, 0>", 168),   # three waves per SIMD
     ("config 2: 4 096 QQube", "k_rollout_ws<QQT<0>, false, true, 1, 4, 64, false, 3, 0>", 168),
-    ("config 3: 65 536 cartpole + live DR", "k_rollout_ws<QcpT<0>, false, true, 1, 4, 64, false, 2, 1>", 256),  # two waves per SIMD
-    ("config 4: 32 768 ball balancer", "k_rollout_ws<Qbb, false, true, 1, 4, 64, false, 2, 0>", 256),
+    ("config 3: 65 536 cartpole + live DR", "k_rollout_ws<QcpT<0>, false, true, 1, 4, 64, false, 3, 1>", 168),
+    ("config 4: 32 768 ball balancer", "k_rollout_ws<Qbb, false, true, 1, 4, 64, false, 2, 0>", 256),  # two waves per SIMD
     ("ball balancer at 65 536", "k_rollout_ws<Qbb, false, true, 1, 4, 256, false, 2, 0>", 256),
     ("config 5: mixed batch", "k_rollout_mixed<true, 1, false>(Segs const*, int, unsigned long)", 128),    # four waves per SIMD
     ("config 1 / policy in the loop: oscillator step", "k_step<Omo, false, false, false, 0, false, false>", 128),

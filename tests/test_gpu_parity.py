@@ -47,7 +47,7 @@ def vs():
 
 # the families that also run the three-role shapes of k_rollout_ws (E::WS_G3: a generator wave beside the physics and the
 # reward wave); pinning those shapes for another family falls back to the two-role shape of the same workgroup size
-G3_FAMILIES = {"qq-su", "qq-st", "omo", "pend"}
+G3_FAMILIES = {"qq-su", "qq-st", "omo", "pend", "qcp-su"}
 
 
 def ws_variants(name):
@@ -1123,8 +1123,8 @@ def test_config3_launch_values_at_65536(vs):
     """BASELINE config 3 as bench.py's `roofline.configs.config3` leg launches it -- 65 536 QCartPoleSwingUpSim envs, the first
     seven parameters of the reference's default randomizer (default_randomizers.py:322-342) redrawn at every reset
     (DomainRandWrapperLive), record mode 1, bench.py's steps per launch, records rotating through three slots -- in the
-    automatic kernel (k_rollout_ws in 64-env workgroups: reset stock with the pre-drawn parameters in LDS) and in 256-env
-    workgroups against the plain kernel: records, done bits, VS_PARAMS, VS_CONSTS, final buffers and episode statistics bit
+    automatic kernel (k_rollout_ws, three roles in 64-env workgroups: the generator wave keeps the reset stock with the pre-drawn
+    parameters in LDS), in the two-role 64-env shape and in 256-env workgroups against the plain kernel: records, done bits, VS_PARAMS, VS_CONSTS, final buffers and episode statistics bit
     for bit.  (Values against the reference: the golden step / reset cases and the randomizer tables, at small n.)"""
     L = vs._lib
     import bench
@@ -1151,7 +1151,7 @@ def test_config3_launch_values_at_65536(vs):
         return e
 
     auto = run(None)
-    assert auto.rollout_variant() == "k_rollout_ws64"  # the automatic choice at this size under a live randomizer
+    assert auto.rollout_variant() == "k_rollout_ws64g"  # the automatic choice at this size under a live randomizer
     a = run("k_rollout")
     tt_a = a.traj_tensors(slots * T)
     cnt = a.episode_stats()[0]
@@ -1160,7 +1160,7 @@ def test_config3_launch_values_at_65536(vs):
     rnd = [vs.param_names("qcp-su").index(sp[0]) for sp in specs]
     reset_lanes = cnt > 0
     assert all(len(np.unique(pa[reset_lanes][:, k])) > reset_lanes.sum() // 2 for k in rnd)
-    for b in (auto, run("k_rollout_ws")):
+    for b in (auto, run("k_rollout_ws64"), run("k_rollout_ws")):
         tt_b = b.traj_tensors(slots * T)
         for key in ("rec", "done"):
             assert torch.equal(tt_a[key], tt_b[key]), (b.rollout_variant(), key)
@@ -1216,7 +1216,7 @@ def test_rollout_variant_selection(vs):
     e.set_randomizer([])
     q = vs.VecSimEnv("qcp-su", 4096, **KW["qcp-su"])
     q.set_randomizer([("gravity_const", "normal", 9.81, 1.0, 1e-4, np.inf)])
-    assert q.rollout_variant() == "k_rollout_ws64"  # BASELINE config 3 at small size
+    assert q.rollout_variant() == "k_rollout_ws64g"  # BASELINE config 3 at small size
     q.close()
     b = vs.VecSimEnv("bob", 4096, **KW["bob"])
     b.set_randomizer([("gravity_const", "normal", 9.81, 1.0, 1e-4, np.inf)])
@@ -1237,7 +1237,7 @@ def test_rollout_variant_selection(vs):
         big.close()
     for name, n, expect in (("omo", 4096, "k_rollout_ws64g"), ("qbb", 4096, "k_rollout_ws64"), ("qbb", 32768, "k_rollout_ws64"),
                             ("qbb", 65536, "k_rollout_ws"), ("qbb", 98304, "k_rollout"), ("qcp-st", 4096, "k_rollout"), ("bob", 65536, "k_rollout_ws"),
-                            ("bob-d", 65536, "k_rollout_ws64"), ("bob", 98304, "k_rollout_ws64"), ("qcp-su", 65536, "k_rollout_ws64"),
+                            ("bob-d", 65536, "k_rollout_ws64"), ("bob", 98304, "k_rollout_ws64"), ("qcp-su", 65536, "k_rollout_ws64g"),
                             ("qcp-su", 98304, "k_rollout"), ("qq-su", 4096, "k_rollout_ws64g"), ("qq-su", 32768, "k_rollout_ws64g"),
                             ("qq-su", 32769, "k_rollout_ws256g"), ("omo", 65536, "k_rollout_ws256g"), ("pend", 16384, "k_rollout_ws64g"),
                             ("qq-st", 65536, "k_rollout_ws256g")):
