@@ -338,6 +338,10 @@ struct BobT : EnvDefaults<1> {
     static constexpr int S = 4, A = 1, O = 4, H = 0, I = 4, P = 8, K = 9, KS = 9;
     static constexpr int REW = REW_SCALED_EXP, RADIAL = -1;
     static constexpr int WS_SHAPE_FULL = V == 0 ? 256 : 64;  // (the discrete action's snap makes its reward wave the longer one)
+    // three waves per 64 envs since round 3 (measured once the kernels had lost their register bloat and the randomizer's unused
+    // redraw): 65 536 envs 2.015e11 (256-env workgroups, two roles) -> 2.10e11, 4 096 envs 1.41e10 -> 1.45e10
+    static constexpr bool WS_G3 = true;
+    static constexpr int WS_G3_FULL = 64;
     // DiscreteSpace.project_to (P/spaces/discrete.py:104-131): an action that is np.isclose to one of the elements is
     // kept as it is, anything else snaps to the closest element (argmin: the first of two equally close ones)
     template <class R>
@@ -790,6 +794,10 @@ struct Qbb : EnvDefaults<2> {
     static constexpr int WS_SHAPE_FULL = 256, WS_SMALL = 128;
     static constexpr bool WS_MID = false;
     static constexpr bool WS_ALONE = true;
+    // three waves per 64 envs since round 3: 65 536 envs 1.075e11 (256-env workgroups, two roles) -> 1.127e11, 4 096 envs
+    // 8.26e9 -> 8.44e9, 32 768 envs (BASELINE config 4) unchanged (6.67e10)
+    static constexpr bool WS_G3 = true;
+    static constexpr int WS_G3_FULL = 64;
     enum { C_AM, C_BEQV, C_JEQ, C_CKIN, C_OFFX, C_OFFY, C_TXP, C_TXN, C_TYP, C_TYN, C_BDR2, C_JBR, C_MR2, C_CKMGR2,
            C_ZETA, C_XMAX, C_CMAX, C_IK_X0, C_IK_Y0 };
     static constexpr int CMAX = C_CMAX;

@@ -47,8 +47,9 @@ BASELINE_KERNELS = [
     ("headline: 65 536 QQube", "k_rollout_ws<QQT<0>, false, true, 1, 4, 256, false, 3, 0>", 168),   # three waves per SIMD
     ("config 2: 4 096 QQube", "k_rollout_ws<QQT<0>, false, true, 1, 4, 64, false, 3, 0>", 168),
     ("config 3: 65 536 cartpole + live DR", "k_rollout_ws<QcpT<0>, false, true, 1, 4, 64, false, 3, 1>", 168),
-    ("config 4: 32 768 ball balancer", "k_rollout_ws<Qbb, false, true, 1, 4, 64, false, 2, 0>", 256),  # two waves per SIMD
-    ("ball balancer at 65 536", "k_rollout_ws<Qbb, false, true, 1, 4, 256, false, 2, 0>", 256),
+    ("config 4: 32 768 ball balancer (and 65 536)", "k_rollout_ws<Qbb, false, true, 1, 4, 64, false, 3, 0>", 168),
+    ("ball balancer, two-role 64-env shape (one wave per SIMD by design)", "k_rollout_ws<Qbb, false, true, 1, 4, 64, false, 2, 0>", 512),
+    ("ball-on-beam at 65 536", "k_rollout_ws<BobT<0>, false, true, 1, 4, 64, false, 3, 0>", 168),
     ("config 5: mixed batch", "k_rollout_mixed<true, 1, false>(Segs const*, int, unsigned long)", 128),    # four waves per SIMD
     ("config 1 / policy in the loop: oscillator step", "k_step<Omo, false, false, false, 0, false, false>", 128),
     ("large-N step", "k_step<QQT<0>, false, true, false, 0, false, true>", 128),

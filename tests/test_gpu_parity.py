@@ -47,7 +47,7 @@ def vs():
 
 # the families that also run the three-role shapes of k_rollout_ws (E::WS_G3: a generator wave beside the physics and the
 # reward wave); pinning those shapes for another family falls back to the two-role shape of the same workgroup size
-G3_FAMILIES = {"qq-su", "qq-st", "omo", "pend", "qcp-su"}
+G3_FAMILIES = {"qq-su", "qq-st", "omo", "pend", "qcp-su", "bob", "bob-d", "qbb"}
 
 
 def ws_variants(name):
@@ -1235,9 +1235,9 @@ def test_rollout_variant_selection(vs):
         big = vs.VecSimEnv("qq-su", n_big, **KW["qq-su"])
         assert big.rollout_variant() == expect, n_big
         big.close()
-    for name, n, expect in (("omo", 4096, "k_rollout_ws64g"), ("qbb", 4096, "k_rollout_ws64"), ("qbb", 32768, "k_rollout_ws64"),
-                            ("qbb", 65536, "k_rollout_ws"), ("qbb", 98304, "k_rollout"), ("qcp-st", 4096, "k_rollout"), ("bob", 65536, "k_rollout_ws"),
-                            ("bob-d", 65536, "k_rollout_ws64"), ("bob", 98304, "k_rollout_ws64"), ("qcp-su", 65536, "k_rollout_ws64g"),
+    for name, n, expect in (("omo", 4096, "k_rollout_ws64g"), ("qbb", 4096, "k_rollout_ws64g"), ("qbb", 32768, "k_rollout_ws64g"),
+                            ("qbb", 65536, "k_rollout_ws64g"), ("qbb", 98304, "k_rollout"), ("qcp-st", 4096, "k_rollout"), ("bob", 65536, "k_rollout_ws64g"),
+                            ("bob-d", 65536, "k_rollout_ws64g"), ("bob", 98304, "k_rollout_ws64"), ("qcp-su", 65536, "k_rollout_ws64g"),
                             ("qcp-su", 98304, "k_rollout"), ("qq-su", 4096, "k_rollout_ws64g"), ("qq-su", 32768, "k_rollout_ws64g"),
                             ("qq-su", 32769, "k_rollout_ws256g"), ("omo", 65536, "k_rollout_ws256g"), ("pend", 16384, "k_rollout_ws64g"),
                             ("qq-st", 65536, "k_rollout_ws256g")):
