@@ -562,6 +562,7 @@ def baseline_config_legs(local_rank, chunk, iters=100):
     import simurlacra_amd as vs
 
     counters = load_counters()
+    preroll = int(os.environ.get("BENCH_PREROLL", "400"))
     legs = {}
     for cfg in BASELINE_CONFIGS:
         try:
@@ -592,7 +593,7 @@ def baseline_config_legs(local_rank, chunk, iters=100):
                         launches[0] += 1
                         e.step_random(chunk, seed=13, record=True)
 
-                go(30)
+                go(preroll + 30)  # (untimed: the headline's pre-roll -- the episodes of the batch out of phase with the common reset -- and warm-up)
                 e.sync()
                 e.timer_start()
                 go(iters)
@@ -606,7 +607,7 @@ def baseline_config_legs(local_rank, chunk, iters=100):
             ach = b_per * units / (ms * 1e-3) / 1e9
             leg = {"config": cfg["what"], "kernel": kname, "envs": n_tot, "env_steps_per_launch": units, "kernel_ms": ms,
                    "env_steps_per_s": units / (ms * 1e-3), "alg_bytes_per_env_step": b_per, "achieved": ach, "unit": "GB/s",
-                   "peak": HBM_PEAK_GBS, "frac": ach / HBM_PEAK_GBS}
+                   "peak": HBM_PEAK_GBS, "frac": ach / HBM_PEAK_GBS, "preroll": preroll if len(envs) == 1 else 0, "warmup": 30, "launches": iters}
             cn = counters_of(counters, cfg["key"], ms)
             if cn:
                 leg["counters"] = cn

@@ -19,7 +19,7 @@ KERNELS = {
     "record2": "k_rollout_ws<vs::QQT<0>,false,true,2,4,256,false,3,0>",
     "config2": "k_rollout_ws<vs::QQT<0>,false,true,1,4,64,false,3,0>",
     "config3": "k_rollout_ws<vs::QcpT<0>,false,true,1,4,64,false,3,1>",
-    "config4": "k_rollout_ws<vs::Qbb,false,true,1,4,64,false,2,0>",
+    "config4": "k_rollout_ws<vs::Qbb,false,true,1,4,64,false,3,0>",
     "config5": "k_rollout_mixed<true,1,false>",
     "large_n": "k_step<vs::QQT<0>,false,true,false,0,false,true>",
     "pack_traj": "k_pack_traj<vs::QQT<0>,2>",
