@@ -248,6 +248,11 @@ struct EnvDefaults {
     // the reward wave's constants may be stale under live randomisation), 2 = ActNorm -> clip -> dead zone (the family
     // then provides dead_zone() and dynamics_core(), and never runs this kernel under live randomisation)
     static constexpr int WS_PREP_C = 0;
+    // ... and whether, in the three-role kernel's 64-env workgroups with NO redraw of domain parameters compiled in (DRK = 0:
+    // the constants cannot change inside a launch), the generator wave pre-processes the actions it draws (same levels): at
+    // small batches every wave has a SIMD to itself, a step lasts as long as the physics wave's dependent chain, and the
+    // generator wave idles a third of its time
+    static constexpr int WS_PREP_G64 = 0;
     // ... and which of its two waves draws the policy's actions when steps are recorded: the physics wave where the other one
     // is the longer (it finishes observe() and stores the records), see k_rollout_ws
     static constexpr bool WS_DRAW_P = false;
@@ -255,7 +260,7 @@ struct EnvDefaults {
     // ahead, keeps the reset stock and stores the first record plane): the families whose physics and reward waves are
     // comparable once the draw is off them (measured at 1 024 .. 65 536 envs, profiles/r02_table_three_roles.txt: QQube -16 %,
     // oscillator / pendulum -10 .. -20 %; ball-on-beam, cartpole and ball balancer, whose physics wave is the long one by
-    // itself, gain nothing and keep two waves)
+    // itself, gained nothing in round 2 -- and 1 .. 5 % at the end of round 3, with 57 .. 141 instead of 119 .. 436 registers)
     static constexpr bool WS_G3 = false;
     // ... and the workgroup shape of the three-role kernel at one workgroup's worth of envs per compute unit (65 536 envs)
     static constexpr int WS_G3_FULL = 256;
@@ -342,6 +347,7 @@ struct BobT : EnvDefaults<1> {
     // redraw): 65 536 envs 2.015e11 (256-env workgroups, two roles) -> 2.10e11, 4 096 envs 1.41e10 -> 1.45e10
     static constexpr bool WS_G3 = true;
     static constexpr int WS_G3_FULL = 64;
+    static constexpr int WS_PREP_G64 = 1;  // 4 096 / 32 768 envs + 6.5 %, 65 536 + 1.5 %
     // DiscreteSpace.project_to (P/spaces/discrete.py:104-131): an action that is np.isclose to one of the elements is
     // kept as it is, anything else snaps to the closest element (argmin: the first of two equally close ones)
     template <class R>
@@ -456,11 +462,22 @@ struct QQT : EnvDefaults<1> {
     }
     __device__ static void act_bounds(const float*, float* lo, float* hi) { hi[0] = 4.5f; lo[0] = -4.5f; }  // MAX_ACT_QQ
     // tr: (sin, cos)(alpha) of the PRE-step state when the caller has them in registers (fused rollout), else nullptr
+    // BASELINE config 2 (4 096 envs): 98 -> 85 vector instructions on the physics wave's chain, 260 -> 241 ns per step (+ 8 %; 32 768 envs + 4 %)
+    static constexpr int WS_PREP_G64 = 2;
     template <class R>
-    __device__ static void dynamics(const Task& T, const float* c, R* s, R*, const R* act, const R* tr) {
-        // dead zone, _step_dynamics :130-131
-        R u = act[0];
-        if (c[C_TH_NEG] <= u && u <= c[C_TH_POS]) u = 0.f;
+    __device__ static void dead_zone(const Task&, const float* c, R* a) {  // _step_dynamics :130-131
+        if (c[C_TH_NEG] <= a[0] && a[0] <= c[C_TH_POS]) a[0] = 0.f;
+    }
+    template <class R>
+    __device__ static void dynamics(const Task& T, const float* c, R* s, R* h, const R* act, const R* tr) {
+        R u[1] = {act[0]};
+        dead_zone(T, c, u);
+        dynamics_core(T, c, s, h, u, tr);
+    }
+    // the step behind the dead zone (ua: the voltage that reaches the motor)
+    template <class R>
+    __device__ static void dynamics_core(const Task& T, const float* c, R* s, R*, const R* ua, const R* tr) {
+        R u = ua[0];
         // _dyn :89-125, evaluated once: the reference's "RK4" re-evaluates _dyn at self.state in every stage (Q1), so
         // k_j differ only in their position-derivative slots and the update collapses to
         //   v' = v + dt a,  p' = p + dt v + dt^2/2 a        (closed form verified against the oracle: max abs diff 0)
@@ -709,6 +726,7 @@ using QcpSt = QcpT<1>;
 // =================================================================================================== Pendulum
 // PendulumSim, P/environments/pysim/pendulum.py:43-117
 struct Pend : EnvDefaults<1> {
+    static constexpr int WS_PREP_G64 = 1;  // 4 096 envs + 4 %
     static constexpr int S = 2, A = 1, O = 3, H = 0, I = 2, P = 5, K = 4, KS = 4;
     // idcs=[1] in the reference (pendulum.py:87): the 2pi modulo is applied to the theta_dot error
     static constexpr int REW = REW_EXP, RADIAL = 1, CMAX = -1;

@@ -1435,9 +1435,10 @@ __attribute__((amdgpu_waves_per_eu(NR == 3 ? 3 : E::WS_MIN_WAVES, (NE == 64 && N
     __shared__ __attribute__((aligned(16))) float l_msg[2][WS_R][M * NE];
     // PC ("prep on C"): the C wave, which draws the actions, also runs ActNorm -> clip -> dead zone on them and hands the P
     // wave the voltages that reach the dynamics, next to the raw action it keeps for its own reward / record
-    constexpr int PCL = DP ? 0 : E::WS_PREP_C;  // 0: no, 1: ActNorm -> clip, 2: + dead zone (see EnvDefaults::WS_PREP_C)
+    // 0: no, 1: ActNorm -> clip, 2: + dead zone (see EnvDefaults::WS_PREP_C / WS_PREP_G64)
+    constexpr int PCL = DP ? 0 : (E::WS_PREP_C > 0 ? E::WS_PREP_C : ((NR == 3 && NE == 64 && DRK == 0) ? E::WS_PREP_G64 : 0));
     constexpr bool PC = PCL > 0;
-    static_assert(PCL != 2 || E::REWARD_SIDE_USES_CONSTS, "a dead zone on the C wave reads per-env constants");
+    static_assert(PCL != 2 || E::REWARD_SIDE_USES_CONSTS || DRK == 0, "a dead zone off the physics wave reads per-env constants: they must not change inside the launch");
     constexpr int AW = PC ? 2 * E::A : E::A;  // floats per step in l_act: [u | a] or [a]
     // two buffers (the C wave draws batch b + 1 after it has worked batch b - 1 off), three when a wave of its own draws:
     // in phase b the G wave writes batch b + 1 while P reads batch b and C still reads the raw actions of batch b - 1
@@ -2399,8 +2400,9 @@ void launch_step_mixed(const Segs* dev_segs, int total_blocks, hipStream_t st, b
 //     (QQube: 72 against 86 us per 100 recorded steps) where the kernel's registers allow a third wave per SIMD (E::WS_MID:
 //     not the cartpole's 224);
 //   * beyond: k_rollout has two or more waves per SIMD by itself;
-//   * the families with E::WS_G3 (QQube, oscillator, pendulum) run THREE waves per 64 envs up to 256 envs per compute unit
-//     (profiles/r02_table_three_roles.txt: QQube at 65 536 envs 44.8 -> 37.7 us, at 4 096 envs 32.7 -> 27.1 us per 100 steps).
+//   * the families with E::WS_G3 (since round 3 every family but the cartpole's stabilisation task) run THREE waves per 64 envs up to
+//     256 envs per compute unit (profiles/r02_table_three_roles.txt: QQube at 65 536 envs 44.8 -> 37.7 us, at 4 096 envs 32.7 -> 27.1 us
+//     per 100 steps; profiles/r03_table_families.txt: cartpole, ball-on-beam, ball balancer + 1 .. 5 %), in the shape E::WS_G3_FULL at 256.
 // VS_ROLLOUT_VARIANT=plain|ws|ws64|g64|g256 overrides for every handle (experiments); vs_set_rollout_variant pins per handle.
 template <class E>
 int Launch<E>::variant(vs_env* h) {
