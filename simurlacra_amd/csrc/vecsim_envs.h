@@ -297,6 +297,7 @@ struct EnvDefaults {
 // =================================================================================================== OMO
 // OneMassOscillatorSim, P/environments/pysim/one_mass_oscillator.py:49-121
 struct Omo : EnvDefaults<1> {
+    static constexpr int WS_PREP_G64 = 1;  // 4 096 envs + 3.7 %, 32 768 + 5 %
     static constexpr int S = 2, A = 1, O = 2, H = 0, I = 2, P = 3, K = 4, KS = 4;
     static constexpr int REW = REW_QUADR, RADIAL = -1, CMAX = -1;
     static constexpr int FINAL = FINAL_CONST_MALUS;  // FinalRewTask(factor 1e3, always_negative), :75-79

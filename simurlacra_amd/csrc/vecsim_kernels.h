@@ -1436,7 +1436,12 @@ __attribute__((amdgpu_waves_per_eu(NR == 3 ? 3 : E::WS_MIN_WAVES, (NE == 64 && N
     // PC ("prep on C"): the C wave, which draws the actions, also runs ActNorm -> clip -> dead zone on them and hands the P
     // wave the voltages that reach the dynamics, next to the raw action it keeps for its own reward / record
     // 0: no, 1: ActNorm -> clip, 2: + dead zone (see EnvDefaults::WS_PREP_C / WS_PREP_G64)
+#ifdef VS_PREP_G256  // (experiment: also in the 256-env shape -- QQube at 65 536 envs - 2 %, oscillator - 1.5 %, pendulum + 1 %: there the generator
+                    // wave is the busiest of the three already)
+    constexpr int PCL = DP ? 0 : (E::WS_PREP_C > 0 ? E::WS_PREP_C : ((NR == 3 && DRK == 0) ? E::WS_PREP_G64 : 0));
+#else
     constexpr int PCL = DP ? 0 : (E::WS_PREP_C > 0 ? E::WS_PREP_C : ((NR == 3 && NE == 64 && DRK == 0) ? E::WS_PREP_G64 : 0));
+#endif
     constexpr bool PC = PCL > 0;
     static_assert(PCL != 2 || E::REWARD_SIDE_USES_CONSTS || DRK == 0, "a dead zone off the physics wave reads per-env constants: they must not change inside the launch");
     constexpr int AW = PC ? 2 * E::A : E::A;  // floats per step in l_act: [u | a] or [a]
