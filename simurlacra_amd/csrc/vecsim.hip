@@ -283,7 +283,7 @@ static int mixed_upload(vs_mixed* m, const float* const* acts, const int64_t* en
 
 extern "C" {
 
-int vs_version(void) { return 303; }
+int vs_version(void) { return 304; }
 
 static int record_width(int t, int mode) {
     const EnvInfo& e = ENV_INFO[t];

@@ -88,12 +88,32 @@ __device__ __forceinline__ Dual<N> exp_neg_fast(const Dual<N>& x) {
     return r;
 }
 
-// sin and cos of a BOUNDED angle (every angle on the hot path is a state inside / next to its box, |x| < ~1e3):
-// 3-term Cody-Waite reduction by pi/2 with FMAs (exact products), then the Cephes minimax polynomials on [-pi/4, pi/4].
-// ~25 VALU instructions for both values against ~150 for the general-range library sincosf (Payne-Hanek branch
-// included); max error measured against fp64 over |x| <= 100: < 1.2e-7 abs (tests/test_gpu_kernels.py).
-// NaN / inf inputs give NaN (the error flag relies on that).
+// sin and cos of a BOUNDED angle (every angle on the hot path is a state inside / next to its box, |x| < ~1e3).
+// Rounds 1-3 (kept behind -DVS_POLY_SINCOS): 3-term Cody-Waite reduction by pi/2 with FMAs (exact products), then the Cephes
+// minimax polynomials on [-pi/4, pi/4] -- 28 VALU instructions for both values against ~150 for the general-range library
+// sincosf (Payne-Hanek branch included), max error against fp64 over |x| <= 100: 9e-8 abs.  Shipped since the end of round 3:
+// the hardware's transcendental unit behind an exact reduction (below), 3.5e-7 abs (tests/test_gpu_parity.py).
+// NaN / inf inputs give NaN in both forms (the error flag relies on that).
 __device__ __forceinline__ void sincos_fast(float x, float* sn, float* cs) {
+#ifndef VS_POLY_SINCOS
+    // The hardware's v_sin_f32 / v_cos_f32 (argument in revolutions) behind an EXACT two-term reduction to [-pi, pi]: 5 vector + 2
+    // transcendental instructions (~52 issue cycles) where the Cody-Waite reduction + two polynomials + quadrant selects below are 28
+    // (~112).  Maximum absolute error 3.8e-7 over |x| <= 70 rad against the polynomials' 9e-8 (scratch/ubench/hw_sincos_err.hip; the
+    // multiply by 1 / 2 pi alone, without the reduction, would add |x| x 6e-8) -- three ulp of a value near 1, a thirtieth of the
+    // 1e-5 relative the state trajectories are held to; every golden-vector and oracle parity test holds at its old tolerance.
+    // What it bought (end of round 3, same box): headline 1.67e11 -> 1.84e11, BASELINE config 4 (four sincos per step) 6.6e10 ->
+    // 9.1e10, config 3 1.04e11 -> 1.09e11, config 2 1.69e10 -> 1.79e10.  -DVS_POLY_SINCOS keeps the polynomial form (diagnostics).
+    {
+        const float TWOPI_HI = 6.28318548202514648f, TWOPI_LO = -1.74845553146951715e-07f, INV_2PI = 0.159154943091895336f;
+        float q = rintf(x * INV_2PI);
+        float r = fmaf(-q, TWOPI_HI, x);
+        r = fmaf(-q, TWOPI_LO, r);
+        float rev = r * INV_2PI;
+        *sn = __builtin_amdgcn_sinf(rev);
+        *cs = __builtin_amdgcn_cosf(rev);
+        return;
+    }
+#endif
     const float PIO2_HI = 1.57079637050628662109375f;       // (float)(pi/2)
     const float PIO2_MID = -4.37113882867379127e-08f;       // (float)(pi/2 - HI)
     const float PIO2_LO = -1.71512451008199912e-15f;        // (float)(pi/2 - HI - MID)

@@ -588,8 +588,11 @@ def test_edge_sizes(vs):
 
 
 def test_fast_sincos_accuracy_through_observe(vs):
-    """the bounded-range sincos of the hot path (vecsim_envs.h: sincos_fast) against fp64 over |angle| <= 100 rad,
-    read back through QQubeSim.observe"""
+    """the sincos of the hot path (vecsim_envs.h: sincos_fast) against fp64 over |angle| <= 100 rad, read back through
+    QQubeSim.observe.  Since the end of round 3 it is the hardware's v_sin_f32 / v_cos_f32 behind an exact two-term reduction:
+    3.5e-7 maximum absolute error measured here (3.8e-7 in scratch/ubench/hw_sincos_err.hip), where the polynomial form it
+    replaced reached 9e-8 and this bound stood at 2e-7 -- a deliberate trade: three ulp of a value near 1,
+    a thirtieth of the 1e-5 relative the trajectories are held to, for 10 % on the headline and 37 % on BASELINE config 4."""
     L = vs._lib
     n = 1 << 16
     env = vs.VecSimEnv("qq-su", n, **KW["qq-su"])
@@ -603,7 +606,7 @@ def test_fast_sincos_accuracy_through_observe(vs):
     s64 = s.astype(np.float64)
     exp = np.stack([np.sin(s64[:, 0]), np.cos(s64[:, 0]), np.sin(s64[:, 1]), np.cos(s64[:, 1])], axis=1)
     err = np.abs(o[:, :4] - exp).max()
-    assert err < 2.0e-7, err
+    assert err < 4.0e-7, err
     env.close()
 
 
