@@ -769,8 +769,9 @@ def roofline(args, env, local_rank, d, n, chunk, ms_region=None):
                 roof["traffic"], roof["traffic_source"] = cn["traffic"], cn["source"]
     roof["note"] = ("at 65 536 envs there is one wave of envs per SIMD: the fused kernel runs three cooperating waves per 64 envs "
                     "(k_rollout_ws: physics | reward + records | action generator + first record plane); its record stream is a "
-                    "pure write stream, whose ceiling on this GPU is `write_kernel_GBs`, not the 8 TB/s of `peak` (DESIGN.md "
-                    "sections 4 and 7); `large_n` is the read + write HBM-bound point of the path") if args.mode == "fused" else \
+                    "pure write stream -- `write_kernel_GBs` is what an in-repo pure-write probe reaches on this GPU, a reference "
+                    "point beside the 8 TB/s of `peak`, not a bound (the kernel passed it once its vector-instruction count came "
+                    "down: DESIGN.md section 7.0); `large_n` is the read + write HBM-bound point of the path") if args.mode == "fused" else \
                    ("one launch per env step; HBM-bound from ~1 M envs, launch-latency-bound at 65 536")
     return roof
 
