@@ -92,7 +92,8 @@ class FNN(torch.nn.Module):
             self.param_values = init_values
 
     def forward(self, obs):
-        x = obs
+        p0 = next(self.parameters(), None)
+        x = obs if p0 is None else obs.to(p0.device)  # (fnn.py: obs.to(self.device); a no-op on the same device, also under graph capture)
         for i, layer in enumerate(self.hidden_layers):
             x = layer(x)
             if self.dropout == 0:

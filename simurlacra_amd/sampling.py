@@ -285,7 +285,9 @@ class ParallelRolloutSampler:
         self._fuse_policy = bool(fuse_policy)
         # graph_policy (opt-in): a policy that stays a torch module is stepped through a captured hipGraph of 32 (observation,
         # policy, recording step) iterations instead of ~10 eager launches per env step -- for policies whose forward() is
-        # capturable (no host synchronisation, no data-dependent Python control flow)
+        # capturable (no host synchronisation, no data-dependent Python control flow).  A deterministic policy gives the eager
+        # path's rollouts bit for bit (test); a stochastic one draws from the same distribution but not the same numbers (the two
+        # warm-up steps before the capture advance torch's generator, and a captured generator offset is replayed per graph launch)
         self._graph_policy = bool(graph_policy)
         # owned_arrays: the arrays of the rollouts sample() returns are pageable copies the caller owns.  Default (False): they
         # are VIEWS of one page-locked block per field and call (~7.7 GB for 65 536 full-record QQube rollouts, 57 GB/s instead
