@@ -1240,7 +1240,7 @@ def test_rollout_variant_selection(vs):
         big.close()
     for name, n, expect in (("omo", 4096, "k_rollout_ws64g"), ("qbb", 4096, "k_rollout_ws64g"), ("qbb", 32768, "k_rollout_ws64g"),
                             ("qbb", 65536, "k_rollout_ws64g"), ("qbb", 98304, "k_rollout"), ("qcp-st", 4096, "k_rollout"), ("bob", 65536, "k_rollout_ws64g"),
-                            ("bob-d", 65536, "k_rollout_ws64g"), ("bob", 98304, "k_rollout_ws64"), ("qcp-su", 65536, "k_rollout_ws64g"),
+                            ("bob-d", 65536, "k_rollout_ws64g"), ("bob", 98304, "k_rollout_ws64g"), ("pend", 98304, "k_rollout_ws64g"), ("qq-st", 98304, "k_rollout_ws64"), ("qcp-su", 65536, "k_rollout_ws64g"),
                             ("qcp-su", 98304, "k_rollout"), ("qq-su", 4096, "k_rollout_ws64g"), ("qq-su", 32768, "k_rollout_ws64g"),
                             ("qq-su", 32769, "k_rollout_ws256g"), ("omo", 65536, "k_rollout_ws256g"), ("pend", 16384, "k_rollout_ws64g"),
                             ("qq-st", 65536, "k_rollout_ws256g")):
