@@ -263,8 +263,9 @@ struct EnvDefaults {
     static constexpr bool WS_MID = true;
     // ... in which shape there: three roles (64-env workgroups: six of them fit a compute unit's LDS) or two.  Measured at the end
     // of round 3 at 81 920 / 98 304 envs (scratch/r3/mid_n.sh): oscillator, ball-on-beam (both forms) and pendulum + 3 .. 14 % with three
-    // roles; the QQube (both tasks) keeps two
-    static constexpr bool WS_MID_G3 = false;
+    // roles from 256 envs per compute unit on, the QQube (both tasks) from 320 on (+ 3 .. 7 %: mid_qq.sh); the value is the number of
+    // envs per compute unit from which the three-role shape is taken
+    static constexpr int WS_MID_G3_FROM = 1 << 30;
     // ... and up to how many envs per compute unit the 64-env workgroups are used whatever WS_SHAPE_FULL says
     static constexpr int WS_SMALL = 64;
     // ... and whether its reward wave, which draws the policy's actions, also pre-processes them for the physics wave, for a
@@ -321,7 +322,7 @@ struct EnvDefaults {
 // =================================================================================================== OMO
 // OneMassOscillatorSim, P/environments/pysim/one_mass_oscillator.py:49-121
 struct Omo : EnvDefaults<1> {
-    static constexpr bool WS_MID_G3 = true;
+    static constexpr int WS_MID_G3_FROM = 0;
     static constexpr int WS_PREP_G64 = 1;  // 4 096 envs + 3.7 %, 32 768 + 5 %
     static constexpr int S = 2, A = 1, O = 2, H = 0, I = 2, P = 3, K = 4, KS = 4;
     static constexpr int REW = REW_QUADR, RADIAL = -1, CMAX = -1;
@@ -366,7 +367,7 @@ struct Omo : EnvDefaults<1> {
 // V = 1: BallOnBeamDiscSim (ball_on_beam.py:139-161): the action space is DiscreteSpace({-max, 0, +max})
 template <int V>
 struct BobT : EnvDefaults<1> {
-    static constexpr bool WS_MID_G3 = true;
+    static constexpr int WS_MID_G3_FROM = 0;
     static constexpr int S = 4, A = 1, O = 4, H = 0, I = 4, P = 8, K = 9, KS = 9;
     static constexpr int REW = REW_SCALED_EXP, RADIAL = -1;
     static constexpr int WS_SHAPE_FULL = V == 0 ? 256 : 64;  // (the discrete action's snap makes its reward wave the longer one)
@@ -464,6 +465,7 @@ using BobD = BobT<1>;
 // V = 1: QQubeStabSim (quanser_qube.py:191-222): same dynamics and spaces, init space around the upright pendulum
 template <int V>
 struct QQT : EnvDefaults<1> {
+    static constexpr int WS_MID_G3_FROM = 320;
     static constexpr int S = 4, A = 1, O = 6, H = 0, I = 4, P = 11, K = 11, KS = 11;
     static constexpr int REW = REW_EXP, RADIAL = 1, CMAX = -1;
     static constexpr bool REWARD_SIDE_USES_CONSTS = false;
@@ -753,7 +755,7 @@ using QcpSt = QcpT<1>;
 // =================================================================================================== Pendulum
 // PendulumSim, P/environments/pysim/pendulum.py:43-117
 struct Pend : EnvDefaults<1> {
-    static constexpr bool WS_MID_G3 = true;
+    static constexpr int WS_MID_G3_FROM = 0;
     static constexpr int WS_PREP_G64 = 1;  // 4 096 envs + 4 %
     static constexpr int S = 2, A = 1, O = 3, H = 0, I = 2, P = 5, K = 4, KS = 4;
     // idcs=[1] in the reference (pendulum.py:87): the 2pi modulo is applied to the theta_dot error

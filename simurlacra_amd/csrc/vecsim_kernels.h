@@ -2433,7 +2433,7 @@ int Launch<E>::variant(vs_env* h) {
     if (ld <= E::WS_SMALL * cu) return RV_WS64;
     if (!E::WS_PAYS) return RV_PLAIN;
     if (ld <= 256 * cu) return live ? RV_WS64 : (E::WS_SHAPE_FULL == 64 ? RV_WS64 : RV_WS256);
-    if (ld <= 384 * cu && E::WS_MID) return (E::WS_G3 && E::WS_MID_G3) ? RV_WS64G : RV_WS64;
+    if (ld <= 384 * cu && E::WS_MID) return (E::WS_G3 && ld > (int64_t)E::WS_MID_G3_FROM * cu) ? RV_WS64G : RV_WS64;
     return RV_PLAIN;
 }
 

@@ -1234,13 +1234,14 @@ def test_rollout_variant_selection(vs):
     e.set_rollout_variant(None)
     assert e.rollout_variant() == "k_rollout_ws256g"
     e.close()
-    for n_big, expect in ((65537, "k_rollout_ws64"), (98304, "k_rollout_ws64"), (98305, "k_rollout"), (131072, "k_rollout")):
+    for n_big, expect in ((65537, "k_rollout_ws64"), (81920, "k_rollout_ws64"), (82176, "k_rollout_ws64g"), (98304, "k_rollout_ws64g"),
+                          (98305, "k_rollout"), (131072, "k_rollout")):
         big = vs.VecSimEnv("qq-su", n_big, **KW["qq-su"])
         assert big.rollout_variant() == expect, n_big
         big.close()
     for name, n, expect in (("omo", 4096, "k_rollout_ws64g"), ("qbb", 4096, "k_rollout_ws64g"), ("qbb", 32768, "k_rollout_ws64g"),
                             ("qbb", 65536, "k_rollout_ws64g"), ("qbb", 98304, "k_rollout"), ("qcp-st", 4096, "k_rollout"), ("bob", 65536, "k_rollout_ws64g"),
-                            ("bob-d", 65536, "k_rollout_ws64g"), ("bob", 98304, "k_rollout_ws64g"), ("pend", 98304, "k_rollout_ws64g"), ("qq-st", 98304, "k_rollout_ws64"), ("qcp-su", 65536, "k_rollout_ws64g"),
+                            ("bob-d", 65536, "k_rollout_ws64g"), ("bob", 98304, "k_rollout_ws64g"), ("pend", 98304, "k_rollout_ws64g"), ("qq-st", 98304, "k_rollout_ws64g"), ("qq-st", 73728, "k_rollout_ws64"), ("qcp-su", 65536, "k_rollout_ws64g"),
                             ("qcp-su", 98304, "k_rollout"), ("qq-su", 4096, "k_rollout_ws64g"), ("qq-su", 32768, "k_rollout_ws64g"),
                             ("qq-su", 32769, "k_rollout_ws256g"), ("omo", 65536, "k_rollout_ws256g"), ("pend", 16384, "k_rollout_ws64g"),
                             ("qq-st", 65536, "k_rollout_ws256g")):
